@@ -1,0 +1,391 @@
+"""Python host side of the MI355X path-tracing core.
+
+Two shared libraries are bound with ctypes:
+
+* ``libhpt.so``       HIP kernels behind the C ABI of ``include/hpt.h``
+* ``libhpt_host.so``  the C++ host classes (Scene / BVHAccel / HipRenderer)
+                      behind ``include/hpt_host.h``
+
+There is no CPU fallback: if a library is missing, or no GPU is present when a
+device call is made, the call raises.  The classes mirror the reference's host
+interface (gpu_path_tracer/CudaRenderer.hpp:9-33, common/Scene.hpp:20-93):
+``Scene.CreateBuiltinScene`` / ``Add`` / ``buildBVH`` and ``HipRenderer`` with
+``spp``, ``num_threads``, ``SetMode``, ``PrepareRender``, ``Render``,
+``FinishRender`` and ``PathTrace``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_PKG)
+DEFAULT_MODELS_DIR = os.path.join(ROOT, "models")
+
+SingleKernel = 1
+Streamed = 2
+FIXED_ONE = 16777216.0  # accumulators are 40.24 fixed point
+
+
+class HptError(RuntimeError):
+    pass
+
+
+class hpt_material(C.Structure):
+    _fields_ = [("type", C.c_int32), ("emission", C.c_float * 3), ("albedo", C.c_float * 3), ("metallic", C.c_float),
+                ("roughness", C.c_float), ("ior", C.c_float), ("_pad", C.c_float * 2)]
+
+
+class hpt_light(C.Structure):
+    _fields_ = [("area", C.c_float), ("root_area", C.c_float), ("root_node", C.c_uint32), ("material", C.c_uint32)]
+
+
+class hpt_scene_desc(C.Structure):
+    _fields_ = [("num_nodes", C.c_uint32), ("nodes", C.POINTER(C.c_float)), ("node_area", C.POINTER(C.c_float)),
+                ("num_tris", C.c_uint32), ("tris", C.POINTER(C.c_float)), ("tri_v12", C.POINTER(C.c_float)),
+                ("num_materials", C.c_uint32), ("materials", C.POINTER(hpt_material)),
+                ("num_lights", C.c_uint32), ("lights", C.POINTER(hpt_light)),
+                ("sum_light_area", C.c_float), ("sum_light_power", C.c_float),
+                ("cam_pos", C.c_float * 3), ("cam_scale", C.c_float), ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class hpt_stats(C.Structure):
+    _fields_ = [("closest_queries", C.c_uint64), ("shadow_queries", C.c_uint64), ("paths", C.c_uint64),
+                ("kernel_ms", C.c_double), ("launches", C.c_uint32), ("_pad", C.c_uint32)]
+
+    def as_dict(self):
+        return dict(closest_queries=int(self.closest_queries), shadow_queries=int(self.shadow_queries),
+                    paths=int(self.paths), kernel_ms=float(self.kernel_ms), launches=int(self.launches))
+
+
+def Material(type=0, emission=(0.0, 0.0, 0.0), albedo=(0.9, 0.9, 0.9), metallic=0.0, roughness=1.0, ior=0.0):
+    """Material with the reference's defaults (common/Material.hpp:137-142).
+    type: 0 Lambertian, 1 MetallicWorkflow."""
+    m = hpt_material()
+    m.type = int(type)
+    m.emission[:] = [float(np.float32(v)) for v in emission]
+    m.albedo[:] = [float(np.float32(v)) for v in albedo]
+    m.metallic, m.roughness, m.ior = float(metallic), float(roughness), float(ior)
+    return m
+
+
+_libs = None
+
+
+def load_libraries():
+    """Load (once) and return (libhpt, libhpt_host)."""
+    global _libs
+    if _libs is not None:
+        return _libs
+    paths = [os.path.join(_PKG, "libhpt.so"), os.path.join(_PKG, "libhpt_host.so")]
+    for p in paths:
+        if not os.path.exists(p):
+            raise HptError("%s is missing: build it with `make hpt host` (or __graft_entry__.build()); "
+                           "there is no CPU fallback" % p)
+    try:
+        hpt = C.CDLL(paths[0], mode=C.RTLD_GLOBAL)
+        host = C.CDLL(paths[1])
+    except OSError as e:
+        raise HptError("cannot load the HIP extension: %s" % e)
+    _declare(hpt, host)
+    _libs = (hpt, host)
+    return _libs
+
+
+def _declare(L, H):
+    vp, i32, u32, u64 = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64
+    L.hpt_last_error.restype = C.c_char_p
+    L.hpt_version.restype = C.c_char_p
+    L.hpt_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.hpt_context_create.argtypes = [i32, C.POINTER(vp)]
+    L.hpt_context_destroy.argtypes = [vp]
+    L.hpt_scene_upload.argtypes = [vp, C.POINTER(hpt_scene_desc)]
+    L.hpt_set_seed.argtypes = [vp, u32]
+    L.hpt_set_wavefront_capacity.argtypes = [vp, u64]
+    L.hpt_accum_clear.argtypes = [vp, vp, vp]
+    L.hpt_render.argtypes = [vp, i32, i32, i32, u32, u32, vp, vp]
+    L.hpt_resolve.argtypes = [vp, vp, u32, vp, vp]
+    L.hpt_resolve_dev.argtypes = [vp, vp, u32, vp, vp]
+    L.hpt_intersect_batch.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, vp, vp]
+    L.hpt_intersect_batch_dev.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, vp, vp, i32, vp]
+    L.hpt_stats_get.argtypes = [vp, C.POINTER(hpt_stats)]
+    L.hpt_stats_reset.argtypes = [vp]
+    L.hpt_accum_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    H.hpt_host_last_error.restype = C.c_char_p
+    H.hpt_host_scene_cornell.argtypes = [C.c_char_p, i32, i32, i32, C.POINTER(vp)]
+    H.hpt_host_scene_create.argtypes = [i32, i32, vp, C.c_double, i32, C.POINTER(vp)]
+    H.hpt_host_scene_add_obj.argtypes = [vp, C.c_char_p, C.POINTER(hpt_material)]
+    H.hpt_host_scene_add_triangles.argtypes = [vp, vp, i32, C.POINTER(hpt_material)]
+    H.hpt_host_scene_build.argtypes = [vp]
+    H.hpt_host_scene_set_resolution.argtypes = [vp, i32, i32]
+    H.hpt_host_scene_destroy.argtypes = [vp]
+    H.hpt_host_scene_describe.argtypes = [vp, C.POINTER(hpt_scene_desc)]
+    H.hpt_host_scene_prim_ids.argtypes = [vp, vp]
+    H.hpt_host_bvh_dump.argtypes = [vp, i32, C.POINTER(C.c_int), vp, vp, vp, vp]
+    H.hpt_host_render.argtypes = [vp, i32, i32, i32, i32, i32, vp, C.POINTER(hpt_stats)]
+    H.hpt_host_save_ppm.argtypes = [C.c_char_p, vp, i32, i32]
+
+
+def _ck(rc):
+    if rc != 0:
+        raise HptError(load_libraries()[0].hpt_last_error().decode())
+
+
+def _ckh(rc):
+    if rc != 0:
+        raise HptError(load_libraries()[1].hpt_host_last_error().decode())
+
+
+def _ptr(x):
+    """numpy array / torch tensor / int / None -> raw address."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data
+    if hasattr(x, "data_ptr"):
+        return x.data_ptr()
+    raise TypeError("cannot take the address of %r" % type(x))
+
+
+def _stream(stream):
+    if stream is None:
+        return None
+    return getattr(stream, "cuda_stream", stream)
+
+
+class Scene:
+    """Host scene (C++ ``Scene``): meshes, camera, light totals, two-level BVH
+    and its flattened form."""
+
+    CornellBox = 0
+
+    def __init__(self, width, height, camPos=(0.0, 0.0, 0.0), fov=40.0, maxDepth=1, _handle=None):
+        self._H = load_libraries()[1]
+        self.width, self.height, self.maxDepth = int(width), int(height), int(maxDepth)
+        self.name = "custom"
+        if _handle is None:
+            cam = np.asarray(camPos, np.float32)
+            h = C.c_void_p()
+            _ckh(self._H.hpt_host_scene_create(self.width, self.height, cam.ctypes.data, float(fov), self.maxDepth,
+                                               C.byref(h)))
+            _handle = h
+        self._h = _handle
+        self._built = False
+
+    @staticmethod
+    def CreateBuiltinScene(sceneId=0, maxDepth=10, width=0, height=0, models_dir=DEFAULT_MODELS_DIR):
+        """Scene::CreateBuiltinScene (common/Scene.cpp:25-73); 512x512 unless a resolution is given."""
+        if sceneId != Scene.CornellBox:
+            raise HptError("Unsupported sceneId")
+        H = load_libraries()[1]
+        h = C.c_void_p()
+        _ckh(H.hpt_host_scene_cornell(models_dir.encode(), int(width), int(height), int(maxDepth), C.byref(h)))
+        s = Scene(width or 512, height or 512, maxDepth=maxDepth, _handle=h)
+        s.name = "Cornell Box"
+        s._built = True
+        return s
+
+    def Add(self, mesh, material):
+        """mesh: path of an OBJ file, or an array of triangle vertices (n, 3, 3)."""
+        if isinstance(mesh, (str, bytes, os.PathLike)):
+            _ckh(self._H.hpt_host_scene_add_obj(self._h, os.fspath(mesh).encode(), C.byref(material)))
+        else:
+            v = np.ascontiguousarray(mesh, np.float32).reshape(-1, 9)
+            _ckh(self._H.hpt_host_scene_add_triangles(self._h, v.ctypes.data, len(v), C.byref(material)))
+        self._built = False
+
+    def buildBVH(self):
+        _ckh(self._H.hpt_host_scene_build(self._h))
+        self._built = True
+        return self
+
+    def set_resolution(self, width, height):
+        _ckh(self._H.hpt_host_scene_set_resolution(self._h, int(width), int(height)))
+        self.width, self.height = int(width), int(height)
+
+    def describe(self):
+        d = hpt_scene_desc()
+        _ckh(self._H.hpt_host_scene_describe(self._h, C.byref(d)))
+        return d
+
+    def flat_arrays(self):
+        """Copies of the flattened arrays as numpy (for inspection and tests)."""
+        d = self.describe()
+        nn, nt = d.num_nodes, d.num_tris
+        prim = np.zeros(nt, np.int32)
+        _ckh(self._H.hpt_host_scene_prim_ids(self._h, prim.ctypes.data))
+        return dict(
+            nodes=np.ctypeslib.as_array(d.nodes, (nn, 8)).copy(),
+            node_area=np.ctypeslib.as_array(d.node_area, (nn,)).copy(),
+            tris=np.ctypeslib.as_array(d.tris, (nt, 16)).copy(),
+            tri_v12=np.ctypeslib.as_array(d.tri_v12, (nt, 8)).copy(),
+            prim_of_tri=prim,
+            lights=[(L.area, L.root_area, L.root_node, L.material) for L in (d.lights[i] for i in range(d.num_lights))],
+            sum_light_area=d.sum_light_area, sum_light_power=d.sum_light_power, cam_scale=d.cam_scale,
+            cam_pos=tuple(d.cam_pos), width=d.width, height=d.height)
+
+    def bvh_dump(self, mesh):
+        n = C.c_int()
+        _ckh(self._H.hpt_host_bvh_dump(self._h, mesh, C.byref(n), None, None, None, None))
+        b, p = np.zeros((n.value, 6), np.float32), np.zeros(n.value, np.int32)
+        a, m = np.zeros(n.value, np.float32), np.zeros(n.value, np.int32)
+        _ckh(self._H.hpt_host_bvh_dump(self._h, mesh, C.byref(n), b.ctypes.data, p.ctypes.data, a.ctypes.data,
+                                       m.ctypes.data))
+        return dict(bounds=b, payload=p, area=a, miss=m)
+
+    def render_cpp(self, spp, max_depth, num_threads=256, mode=SingleKernel, device=0):
+        """Render through the C++ HipRenderer class (PrepareRender/Render/FinishRender)."""
+        rgb = np.zeros((self.width * self.height, 3), np.float32)
+        st = hpt_stats()
+        _ckh(self._H.hpt_host_render(self._h, device, spp, max_depth, num_threads, mode, rgb.ctypes.data, C.byref(st)))
+        return rgb, st.as_dict()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._H.hpt_host_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Context:
+    """One GPU: uploaded scene, accumulation buffer, ray counters (``hpt_ctx``)."""
+
+    def __init__(self, device=0):
+        self._L = load_libraries()[0]
+        h = C.c_void_p()
+        _ck(self._L.hpt_context_create(int(device), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+        self.width = self.height = 0
+
+    def upload(self, scene):
+        d = scene.describe() if isinstance(scene, Scene) else scene
+        _ck(self._L.hpt_scene_upload(self._h, C.byref(d)))
+        self.width, self.height = d.width, d.height
+        return self
+
+    def set_seed(self, seed):
+        _ck(self._L.hpt_set_seed(self._h, int(seed)))
+
+    def set_wavefront_capacity(self, paths):
+        _ck(self._L.hpt_set_wavefront_capacity(self._h, int(paths)))
+
+    def accum_clear(self, accum=None, stream=None):
+        _ck(self._L.hpt_accum_clear(self._h, _ptr(accum), _stream(stream)))
+
+    def render(self, mode, block, max_depth, sample_begin, sample_count, accum=None, stream=None):
+        _ck(self._L.hpt_render(self._h, int(mode), int(block), int(max_depth), int(sample_begin), int(sample_count),
+                               _ptr(accum), _stream(stream)))
+
+    def resolve(self, spp_total, accum=None, stream=None):
+        rgb = np.zeros((self.width * self.height, 3), np.float32)
+        _ck(self._L.hpt_resolve(self._h, _ptr(accum), int(spp_total), rgb.ctypes.data, _stream(stream)))
+        return rgb
+
+    def resolve_dev(self, spp_total, rgb_dev, accum=None, stream=None):
+        _ck(self._L.hpt_resolve_dev(self._h, _ptr(accum), int(spp_total), _ptr(rgb_dev), _stream(stream)))
+
+    def accum_buffer(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        _ck(self._L.hpt_accum_buffer(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def intersect(self, o, d, shadow=None, tmax=None):
+        """Host arrays in, (prim int32[n], t float64[n]) out."""
+        o = np.ascontiguousarray(o, np.float32)
+        d = np.ascontiguousarray(d, np.float32)
+        n = len(o)
+        sh = None if shadow is None else np.ascontiguousarray(shadow, np.uint8)
+        tm = None if tmax is None else np.ascontiguousarray(tmax, np.float64)
+        prim, t = np.zeros(n, np.int32), np.zeros(n, np.float64)
+        _ck(self._L.hpt_intersect_batch(self._h, n, _ptr(o), _ptr(d), _ptr(sh), _ptr(tm), _ptr(prim), _ptr(t)))
+        return prim, t
+
+    def intersect_dev(self, n, o, d, prim, t, shadow=None, tmax=None, block=256, stream=None):
+        """Device pointers / torch tensors; asynchronous on ``stream``."""
+        _ck(self._L.hpt_intersect_batch_dev(self._h, int(n), _ptr(o), _ptr(d), _ptr(shadow), _ptr(tmax), _ptr(prim),
+                                            _ptr(t), int(block), _stream(stream)))
+
+    def stats(self):
+        st = hpt_stats()
+        _ck(self._L.hpt_stats_get(self._h, C.byref(st)))
+        return st.as_dict()
+
+    def stats_reset(self):
+        _ck(self._L.hpt_stats_reset(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.hpt_context_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HipRenderer:
+    """Python mirror of the C++ ``HipRenderer`` (the reference's ``CudaRenderer``,
+    gpu_path_tracer/CudaRenderer.hpp:15-33)."""
+
+    def __init__(self, device=0):
+        self.spp = 32
+        self.num_threads = 256
+        self.framebuffer = None
+        self.device = device
+        self._mode = SingleKernel
+        self._ctx = None
+
+    def SetMode(self, mode):
+        if mode not in (SingleKernel, Streamed):
+            raise HptError("mode must be 1 (SingleKernel) or 2 (Streamed)")
+        self._mode = mode
+
+    def PrepareRender(self, scene):
+        self.FinishRender(scene)
+        self._ctx = Context(self.device).upload(scene)
+        self.framebuffer = np.zeros((scene.width * scene.height, 3), np.float32)
+
+    def Render(self, scene):
+        if self._ctx is None:
+            raise HptError("HipRenderer.Render: PrepareRender has not been called")
+        self._ctx.accum_clear()
+        if self.spp > 0:
+            self._ctx.render(self._mode, self.num_threads, scene.maxDepth, 0, self.spp)
+            self.framebuffer = self._ctx.resolve(self.spp)
+        return self.framebuffer
+
+    def PathTrace(self, scene, iter):
+        if self._ctx is None:
+            raise HptError("HipRenderer.PathTrace: PrepareRender has not been called")
+        self._ctx.render(self._mode, self.num_threads, scene.maxDepth, iter, 1)
+        self.framebuffer = self._ctx.resolve(max(self.spp, 1))
+
+    def Stats(self):
+        return self._ctx.stats() if self._ctx else {}
+
+    def FinishRender(self, scene=None):
+        if self._ctx is not None:
+            self._ctx.close()
+            self._ctx = None
+
+
+def SavePPM(path, framebuffer, width, height):
+    """Utility::SavePPM (common/Utility.cpp:4-22)."""
+    rgb = np.ascontiguousarray(framebuffer, np.float32)
+    _ckh(load_libraries()[1].hpt_host_save_ppm(os.fspath(path).encode(), rgb.ctypes.data, int(width), int(height)))
+
+
+def device_count():
+    n = C.c_int()
+    _ck(load_libraries()[0].hpt_device_count(C.byref(n)))
+    return n.value

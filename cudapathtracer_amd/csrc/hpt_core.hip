@@ -1,0 +1,764 @@
+// gfx950 kernels and the C ABI (include/hpt.h) of the path-tracing core.
+//
+// Kernels
+//   k_intersect_batch  closest/any-hit queries on a caller-supplied ray batch
+//   k_render_mega      mode 1: one lane per pixel runs whole paths; a lane whose
+//                      path ends starts its next sample at once, so the wave
+//                      stays full although path lengths differ from 1 to
+//                      max_depth bounces
+//   k_wf_generate / k_wf_extend / k_wf_shade
+//                      mode 2: wavefront; path state lives in 64-byte SoA
+//                      records, survivors are compacted with a wave ballot +
+//                      prefix count and one atomic per wave, the live count
+//                      stays on the device (no host round trip per bounce)
+//   k_resolve          fixed-point accumulators -> float RGB / spp
+//
+// Scenes whose node+triangle records fit in kLdsLimit bytes are staged into
+// LDS once per workgroup (the Cornell box: 4 KiB); larger ones are read
+// through L1/L2.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "hpt_device.h"
+
+using namespace hpt;
+
+namespace {
+
+constexpr uint32_t kLdsLimit = 32u * 1024u;
+constexpr int kStatClosest = 0, kStatShadow = 1, kStatPaths = 2, kNumStats = 4;
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return fail(HPT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// ------------------------------------------------------------------ kernels --
+
+// pixel owned by a global lane index: 8x8 pixel tiles, one tile per wave, so
+// that the 64 primary rays of a wave are coherent and neighbouring pixels
+// (similar path-length statistics) share a wave
+__device__ __forceinline__ bool lane_to_pixel(const DevScene& S, uint32_t g, uint32_t& pixel) {
+    const uint32_t tiles_x = ((uint32_t)S.width + 7u) >> 3;
+    const uint32_t tile = g >> 6, lane = g & 63u;
+    const uint32_t x = (tile % tiles_x) * 8u + (lane & 7u), y = (tile / tiles_x) * 8u + (lane >> 3);
+    pixel = y * (uint32_t)S.width + x;
+    return x < (uint32_t)S.width && y < (uint32_t)S.height;
+}
+
+template <bool kLds>
+__global__ void k_intersect_batch(DevScene S, size_t n, const float* __restrict__ o, const float* __restrict__ d,
+                                  const uint8_t* __restrict__ shadow, const double* __restrict__ tmax,
+                                  int32_t* __restrict__ prim, double* __restrict__ t_out) {
+    extern __shared__ float4 lds[];
+    if constexpr (kLds) stage_scene_lds(S, lds);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) {
+        const f3 ro = mk(o[3 * r], o[3 * r + 1], o[3 * r + 2]);
+        const f3 rd = mk(d[3 * r], d[3 * r + 1], d[3 * r + 2]);
+        int tri;
+        double t;
+        if (shadow && shadow[r]) trace<kLds, true>(S, lds, ro, rd, tmax[r], tri, t);
+        else trace<kLds, false>(S, lds, ro, rd, 0.0, tri, t);
+        prim[r] = tri < 0 ? -1 : __float_as_int(S.tris[4 * tri + 2].w);
+        t_out[r] = t;
+    }
+}
+
+__device__ __forceinline__ void accumulate_pixel(int64_t* accum, uint32_t pixel, f3 rad) {
+    unsigned long long* a = reinterpret_cast<unsigned long long*>(accum) + 3ull * pixel;
+    atomicAdd(a + 0, (unsigned long long)radiance_to_fixed(rad.x));
+    atomicAdd(a + 1, (unsigned long long)radiance_to_fixed(rad.y));
+    atomicAdd(a + 2, (unsigned long long)radiance_to_fixed(rad.z));
+}
+
+template <bool kLds, int kMaxBlock>
+__global__ void __launch_bounds__(kMaxBlock)
+k_render_mega(DevScene S, int max_depth, uint32_t s_begin, uint32_t s_end, int64_t* __restrict__ accum,
+              unsigned long long* __restrict__ stats) {
+    extern __shared__ float4 lds[];
+    if constexpr (kLds) stage_scene_lds(S, lds);
+    uint32_t pixel;
+    const bool valid = lane_to_pixel(S, blockIdx.x * blockDim.x + threadIdx.x, pixel);
+    uint32_t n_closest = 0, n_shadow = 0, n_paths = 0;
+    if (valid) {
+        long long acc_r = 0, acc_g = 0, acc_b = 0;
+        uint32_t s = s_begin;
+        bool alive = false;
+        Path p;
+        while (alive || s < s_end) {
+            if (!alive) {
+                generate_camera_path(S, pixel, s, p);
+                ++s;
+                ++n_paths;
+                alive = true;
+            }
+            int tri;
+            double t;
+            ++n_closest;
+            trace<kLds, false>(S, lds, p.o, p.d, 0.0, tri, t);
+            alive = shade_bounce<kLds>(S, lds, p, tri, t, n_shadow) && p.depth < max_depth;
+            if (!alive) {
+                acc_r += radiance_to_fixed(p.rad.x);
+                acc_g += radiance_to_fixed(p.rad.y);
+                acc_b += radiance_to_fixed(p.rad.z);
+            }
+        }
+        unsigned long long* a = reinterpret_cast<unsigned long long*>(accum) + 3ull * pixel;
+        atomicAdd(a + 0, (unsigned long long)acc_r);
+        atomicAdd(a + 1, (unsigned long long)acc_g);
+        atomicAdd(a + 2, (unsigned long long)acc_b);
+    }
+    atomicAdd(stats + kStatClosest, (unsigned long long)n_closest);
+    atomicAdd(stats + kStatShadow, (unsigned long long)n_shadow);
+    atomicAdd(stats + kStatPaths, (unsigned long long)n_paths);
+}
+
+// ---- wavefront: 64-byte path records as four float4 planes -----------------
+struct WfQueue {
+    float4* a;  // o.xyz, bsdfSamplePdf
+    float4* b;  // d.xyz, bits(pixel)
+    float4* c;  // throughput.xyz, bits(sample)
+    float4* d;  // radiance.xyz, bits(depth | specular << 31)
+};
+__device__ __forceinline__ void wf_store(const WfQueue& q, size_t i, const Path& p) {
+    q.a[i] = make_float4(p.o.x, p.o.y, p.o.z, p.pdf);
+    q.b[i] = make_float4(p.d.x, p.d.y, p.d.z, __uint_as_float(p.pixel));
+    q.c[i] = make_float4(p.thr.x, p.thr.y, p.thr.z, __uint_as_float(p.sample));
+    q.d[i] = make_float4(p.rad.x, p.rad.y, p.rad.z, __uint_as_float((uint32_t)p.depth | (p.specular ? 0x80000000u : 0u)));
+}
+__device__ __forceinline__ void wf_load(const WfQueue& q, size_t i, Path& p) {
+    const float4 a = q.a[i], b = q.b[i], c = q.c[i], d = q.d[i];
+    p.o = mk(a.x, a.y, a.z);
+    p.pdf = a.w;
+    p.d = mk(b.x, b.y, b.z);
+    p.pixel = __float_as_uint(b.w);
+    p.thr = mk(c.x, c.y, c.z);
+    p.sample = __float_as_uint(c.w);
+    p.rad = mk(d.x, d.y, d.z);
+    const uint32_t f = __float_as_uint(d.w);
+    p.depth = (int)(f & 0x7FFFFFFFu);
+    p.specular = (f >> 31) != 0;
+}
+
+// GenerateCameraRay (gpu_path_tracer/CudaPathTrace.cu:34-62) for paths
+// [first, first + count) of the batch's linear path index space
+// (sample-major; the low index walks 8x8 pixel tiles).
+__global__ void k_wf_generate(DevScene S, uint32_t s_begin, uint64_t first, uint32_t count, uint32_t lanes_per_sample,
+                              WfQueue q, uint32_t* __restrict__ live_count, unsigned long long* __restrict__ stats) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    uint32_t made = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const uint64_t g = first + i;
+        const uint32_t s = s_begin + (uint32_t)(g / lanes_per_sample);
+        uint32_t pixel;
+        const bool valid = lane_to_pixel(S, (uint32_t)(g % lanes_per_sample), pixel);
+        // lanes of partial edge tiles own no pixel: they get a dead record
+        // (depth = max) that the first shade pass drops without tracing
+        Path p;
+        if (valid) {
+            generate_camera_path(S, pixel, s, p);
+            ++made;
+        } else {
+            p.o = p.d = p.thr = p.rad = mk(0.f);
+            p.pdf = 0.f;
+            p.depth = 0x7FFFFFFF;
+            p.specular = false;
+            p.pixel = 0xFFFFFFFFu;
+            p.sample = s;
+        }
+        wf_store(q, i, p);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *live_count = count;
+    atomicAdd(stats + kStatPaths, (unsigned long long)made);
+}
+
+// ComputeIntersections (gpu_path_tracer/CudaPathTrace.cu:64-78)
+template <bool kLds>
+__global__ void __launch_bounds__(256)
+k_wf_extend(DevScene S, WfQueue q, const uint32_t* __restrict__ live_count, int2* __restrict__ hits,
+            unsigned long long* __restrict__ stats) {
+    extern __shared__ float4 lds[];
+    if constexpr (kLds) stage_scene_lds(S, lds);
+    const uint32_t count = *live_count;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    uint32_t n_closest = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const float4 a = q.a[i], b = q.b[i];
+        int tri = -1;
+        double t = (double)kInfinity;
+        if (__float_as_uint(b.w) != 0xFFFFFFFFu) {
+            ++n_closest;
+            trace<kLds, false>(S, lds, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), 0.0, tri, t);
+        }
+        hits[i] = make_int2(tri, __float_as_int((float)t));
+    }
+    atomicAdd(stats + kStatClosest, (unsigned long long)n_closest);
+}
+
+// IntegratePathSegment + the two thrust compactions + FinalGather
+// (gpu_path_tracer/CudaPathTrace.cu:80-111, :149-157) in one pass: shade,
+// then either append the survivor to the next queue or add the finished
+// path's radiance to its pixel.
+template <bool kLds>
+__global__ void __launch_bounds__(256)
+k_wf_shade(DevScene S, int max_depth, WfQueue q_in, const int2* __restrict__ hits, const uint32_t* __restrict__ live_in,
+           WfQueue q_out, uint32_t* __restrict__ live_out, int64_t* __restrict__ accum,
+           unsigned long long* __restrict__ stats) {
+    extern __shared__ float4 lds[];
+    if constexpr (kLds) stage_scene_lds(S, lds);
+    const uint32_t count = *live_in;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t n_shadow = 0;
+    // all lanes of a wave run the same number of iterations so that the
+    // ballot below always sees the whole wave
+    const uint32_t wave_first = (blockIdx.x * blockDim.x + threadIdx.x) - lane;
+    for (uint32_t base = wave_first; base < count; base += stride) {
+        const uint32_t i = base + lane;
+        bool keep = false;
+        Path p;
+        if (i < count) {
+            wf_load(q_in, i, p);
+            if (p.pixel != 0xFFFFFFFFu) {
+                const int2 h = hits[i];
+                // the float conversion of t happens here in the single-kernel
+                // path as well (Ray::operator() narrows t, Ray.hpp:27)
+                keep = shade_bounce<kLds>(S, lds, p, h.x, (double)__int_as_float(h.y), n_shadow) && p.depth < max_depth;
+                if (!keep) accumulate_pixel(accum, p.pixel, p.rad);
+            }
+        }
+        const unsigned long long mask = __ballot(keep);
+        if (mask) {
+            const int leader = __ffsll((long long)mask) - 1;
+            uint32_t slot = 0;
+            if ((int)lane == leader) slot = atomicAdd(live_out, (uint32_t)__popcll(mask));
+            slot = __shfl(slot, leader);
+            if (keep) wf_store(q_out, slot + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)), p);
+        }
+    }
+    atomicAdd(stats + kStatShadow, (unsigned long long)n_shadow);
+}
+
+__global__ void k_resolve(const int64_t* __restrict__ accum, size_t n, double denom, float* __restrict__ rgb) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        rgb[i] = (float)((double)accum[i] / denom);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ context --
+
+struct hpt_ctx {
+    int device = 0;
+    int num_cus = 256;
+    bool has_scene = false;
+    DevScene S{};
+    // scene arrays (device)
+    float4* d_nodes = nullptr;
+    float* d_node_area = nullptr;
+    float4* d_tris = nullptr;
+    float4* d_tri_v12 = nullptr;
+    hpt_material* d_mats = nullptr;
+    hpt_light* d_lights = nullptr;
+    // accumulation + stats
+    int64_t* d_accum = nullptr;
+    size_t accum_elems = 0;
+    unsigned long long* d_stats = nullptr;
+    float* d_rgb = nullptr;  // staging for hpt_resolve
+    // wavefront state
+    uint64_t wf_capacity = 1ull << 22;
+    uint64_t wf_allocated = 0;
+    float4* d_wf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int2* d_hits = nullptr;
+    uint32_t* d_live = nullptr;  // per-bounce live counters
+    int live_slots = 0;
+    // timing
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;
+    std::vector<hipEvent_t> free_events;
+    double kernel_ms = 0.0;
+    uint32_t launches = 0;
+    uint32_t spp_per_launch = 64;
+};
+
+namespace {
+
+int set_device(hpt_ctx* ctx) {
+    HIP_TRY(hipSetDevice(ctx->device));
+    return HPT_OK;
+}
+
+void free_scene(hpt_ctx* ctx) {
+    (void)hipFree(ctx->d_nodes);
+    (void)hipFree(ctx->d_node_area);
+    (void)hipFree(ctx->d_tris);
+    (void)hipFree(ctx->d_tri_v12);
+    (void)hipFree(ctx->d_mats);
+    (void)hipFree(ctx->d_lights);
+    (void)hipFree(ctx->d_accum);
+    (void)hipFree(ctx->d_rgb);
+    ctx->d_nodes = nullptr;
+    ctx->d_node_area = nullptr;
+    ctx->d_tris = nullptr;
+    ctx->d_tri_v12 = nullptr;
+    ctx->d_mats = nullptr;
+    ctx->d_lights = nullptr;
+    ctx->d_accum = nullptr;
+    ctx->d_rgb = nullptr;
+    ctx->accum_elems = 0;
+    ctx->has_scene = false;
+}
+
+void free_wavefront(hpt_ctx* ctx) {
+    for (auto& p : ctx->d_wf) {
+        (void)hipFree(p);
+        p = nullptr;
+    }
+    (void)hipFree(ctx->d_hits);
+    (void)hipFree(ctx->d_live);
+    ctx->d_hits = nullptr;
+    ctx->d_live = nullptr;
+    ctx->wf_allocated = 0;
+    ctx->live_slots = 0;
+}
+
+int ensure_wavefront(hpt_ctx* ctx, uint64_t paths, int max_depth) {
+    if (ctx->wf_allocated < paths) {
+        for (auto& p : ctx->d_wf) {
+            (void)hipFree(p);
+            p = nullptr;
+        }
+        (void)hipFree(ctx->d_hits);
+        ctx->d_hits = nullptr;
+        ctx->wf_allocated = 0;
+        for (auto& p : ctx->d_wf) HIP_TRY(hipMalloc((void**)&p, paths * sizeof(float4)));
+        HIP_TRY(hipMalloc((void**)&ctx->d_hits, paths * sizeof(int2)));
+        ctx->wf_allocated = paths;
+    }
+    if (ctx->live_slots < max_depth + 1) {
+        (void)hipFree(ctx->d_live);
+        ctx->d_live = nullptr;
+        ctx->live_slots = 0;
+        HIP_TRY(hipMalloc((void**)&ctx->d_live, (size_t)(max_depth + 1) * sizeof(uint32_t)));
+        ctx->live_slots = max_depth + 1;
+    }
+    return HPT_OK;
+}
+
+// validate the flattened tree on the host so that no kernel can walk out of
+// bounds or loop forever on a malformed upload
+int validate_scene(const hpt_scene_desc* sc) {
+    if (!sc) return fail(HPT_ERR_INVALID_ARGUMENT, "scene is null");
+    if (sc->width <= 0 || sc->height <= 0 || (uint64_t)sc->width * (uint64_t)sc->height > (1ull << 28))
+        return fail(HPT_ERR_INVALID_ARGUMENT, "bad resolution %dx%d", sc->width, sc->height);
+    if (sc->num_nodes == 0 || sc->num_tris == 0 || !sc->nodes || !sc->tris || !sc->tri_v12 || !sc->node_area)
+        return fail(HPT_ERR_INVALID_ARGUMENT, "scene has no nodes/triangles");
+    if (sc->num_nodes > (1u << 30) || sc->num_tris > (1u << 29)) return fail(HPT_ERR_INVALID_ARGUMENT, "scene too large");
+    if (sc->num_materials == 0 || !sc->materials) return fail(HPT_ERR_INVALID_ARGUMENT, "scene has no materials");
+    if (sc->num_lights && !sc->lights) return fail(HPT_ERR_INVALID_ARGUMENT, "lights pointer is null");
+    for (uint32_t m = 0; m < sc->num_materials; ++m)
+        if (sc->materials[m].type < 0 || sc->materials[m].type > 1)
+            return fail(HPT_ERR_INVALID_ARGUMENT, "material %u: type %d is not traced on the device (0 Lambertian, 1 MetallicWorkflow)", m,
+                        sc->materials[m].type);
+    const int32_t nn = (int32_t)sc->num_nodes;
+    std::vector<uint8_t> tri_seen(sc->num_tris, 0);
+    for (int32_t i = 0; i < nn; ++i) {
+        int32_t miss, tri;
+        std::memcpy(&miss, &sc->nodes[8 * (size_t)i + 3], 4);
+        std::memcpy(&tri, &sc->nodes[8 * (size_t)i + 7], 4);
+        if (miss <= i || miss > nn) return fail(HPT_ERR_INVALID_ARGUMENT, "node %d: miss link %d does not point forward", i, miss);
+        if (tri >= (int32_t)sc->num_tris) return fail(HPT_ERR_INVALID_ARGUMENT, "node %d: triangle %d out of range", i, tri);
+        if (tri >= 0) {
+            if (miss != i + 1) return fail(HPT_ERR_INVALID_ARGUMENT, "leaf %d: miss link must be the next node", i);
+            tri_seen[tri] = 1;
+        } else {
+            // interior: left child = i+1, right child = miss link of the left child
+            if (i + 1 >= nn) return fail(HPT_ERR_INVALID_ARGUMENT, "interior node %d has no children", i);
+            int32_t lmiss;
+            std::memcpy(&lmiss, &sc->nodes[8 * (size_t)(i + 1) + 3], 4);
+            if (lmiss <= i + 1 || lmiss >= nn || lmiss >= miss)
+                return fail(HPT_ERR_INVALID_ARGUMENT, "interior node %d: right child %d outside its subtree", i, lmiss);
+        }
+    }
+    for (uint32_t t = 0; t < sc->num_tris; ++t) {
+        int32_t mat;
+        std::memcpy(&mat, &sc->tris[16 * (size_t)t + 7], 4);
+        if (mat < 0 || mat >= (int32_t)sc->num_materials) return fail(HPT_ERR_INVALID_ARGUMENT, "triangle %u: material %d out of range", t, mat);
+    }
+    for (uint32_t l = 0; l < sc->num_lights; ++l) {
+        if (sc->lights[l].root_node >= sc->num_nodes || sc->lights[l].material >= sc->num_materials)
+            return fail(HPT_ERR_INVALID_ARGUMENT, "light %u: bad node/material index", l);
+    }
+    return HPT_OK;
+}
+
+hipEvent_t take_event(hpt_ctx* ctx) {
+    if (!ctx->free_events.empty()) {
+        hipEvent_t e = ctx->free_events.back();
+        ctx->free_events.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+int settle_events(hpt_ctx* ctx) {
+    for (auto& pr : ctx->pending_events) {
+        HIP_TRY(hipEventSynchronize(pr.second));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+        ctx->kernel_ms += ms;
+        ctx->free_events.push_back(pr.first);
+        ctx->free_events.push_back(pr.second);
+    }
+    ctx->pending_events.clear();
+    return HPT_OK;
+}
+
+uint32_t lds_bytes(const DevScene& S) { return S.lds_float4s * 16u; }
+
+int grid_for(const hpt_ctx* ctx, uint64_t work, int block) {
+    // grid-stride kernels: twice the workgroups that are resident at full
+    // occupancy (2048 lanes per CU), never more than the work needs
+    const uint64_t want = (work + (uint64_t)block - 1) / (uint64_t)block;
+    const uint64_t per_cu = 2048ull / (uint64_t)(block < 64 ? 64 : block);
+    const uint64_t cap = (uint64_t)ctx->num_cus * (per_cu ? per_cu : 1ull) * 2ull;
+    return (int)(want < cap ? (want ? want : 1) : cap);
+}
+
+}  // namespace
+
+// --------------------------------------------------------------------- ABI --
+
+extern "C" {
+
+const char* hpt_last_error(void) { return g_last_error.c_str(); }
+const char* hpt_version(void) { return "hpt 0.1 (gfx950)"; }
+
+int hpt_device_count(int* count) {
+    if (!count) return fail(HPT_ERR_INVALID_ARGUMENT, "count is null");
+    HIP_TRY(hipGetDeviceCount(count));
+    return HPT_OK;
+}
+
+int hpt_context_create(int device, hpt_ctx** out) {
+    if (!out) return fail(HPT_ERR_INVALID_ARGUMENT, "out is null");
+    *out = nullptr;
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(HPT_ERR_INVALID_ARGUMENT, "device %d out of range (have %d)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    hpt_ctx* ctx = new hpt_ctx();
+    ctx->device = device;
+    ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char* e = getenv("HPT_SPP_PER_LAUNCH")) {
+        int v = atoi(e);
+        if (v > 0) ctx->spp_per_launch = (uint32_t)v;
+    }
+    hipError_t e = hipMalloc((void**)&ctx->d_stats, kNumStats * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(ctx->d_stats, 0, kNumStats * sizeof(unsigned long long));
+    if (e != hipSuccess) {
+        delete ctx;
+        return fail(HPT_ERR_HIP, "stats buffer: %s", hipGetErrorString(e));
+    }
+    *out = ctx;
+    return HPT_OK;
+}
+
+int hpt_context_destroy(hpt_ctx* ctx) {
+    if (!ctx) return HPT_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    (void)settle_events(ctx);
+    for (hipEvent_t e : ctx->free_events) (void)hipEventDestroy(e);
+    free_scene(ctx);
+    free_wavefront(ctx);
+    (void)hipFree(ctx->d_stats);
+    delete ctx;
+    return HPT_OK;
+}
+
+int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* sc) {
+    if (!ctx) return fail(HPT_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (int rc = validate_scene(sc)) return rc;
+    if (int rc = set_device(ctx)) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    free_scene(ctx);
+    const size_t nn = sc->num_nodes, nt = sc->num_tris;
+    HIP_TRY(hipMalloc((void**)&ctx->d_nodes, nn * 32));
+    HIP_TRY(hipMalloc((void**)&ctx->d_node_area, nn * 4));
+    HIP_TRY(hipMalloc((void**)&ctx->d_tris, nt * 64));
+    HIP_TRY(hipMalloc((void**)&ctx->d_tri_v12, nt * 32));
+    HIP_TRY(hipMalloc((void**)&ctx->d_mats, sc->num_materials * sizeof(hpt_material)));
+    HIP_TRY(hipMalloc((void**)&ctx->d_lights, (sc->num_lights ? sc->num_lights : 1) * sizeof(hpt_light)));
+    HIP_TRY(hipMemcpy(ctx->d_nodes, sc->nodes, nn * 32, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_node_area, sc->node_area, nn * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_tris, sc->tris, nt * 64, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_tri_v12, sc->tri_v12, nt * 32, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_mats, sc->materials, sc->num_materials * sizeof(hpt_material), hipMemcpyHostToDevice));
+    if (sc->num_lights) HIP_TRY(hipMemcpy(ctx->d_lights, sc->lights, sc->num_lights * sizeof(hpt_light), hipMemcpyHostToDevice));
+    ctx->accum_elems = 3ull * (size_t)sc->width * (size_t)sc->height;
+    HIP_TRY(hipMalloc((void**)&ctx->d_accum, ctx->accum_elems * sizeof(int64_t)));
+    HIP_TRY(hipMemset(ctx->d_accum, 0, ctx->accum_elems * sizeof(int64_t)));
+    HIP_TRY(hipMalloc((void**)&ctx->d_rgb, ctx->accum_elems * sizeof(float)));
+
+    DevScene& S = ctx->S;
+    const uint32_t seed = S.seed;
+    S = DevScene{};
+    S.nodes = ctx->d_nodes;
+    S.node_area = ctx->d_node_area;
+    S.tris = ctx->d_tris;
+    S.tri_v12 = ctx->d_tri_v12;
+    S.mats = ctx->d_mats;
+    S.lights = ctx->d_lights;
+    S.num_nodes = sc->num_nodes;
+    S.num_tris = sc->num_tris;
+    S.num_mats = sc->num_materials;
+    S.num_lights = sc->num_lights;
+    S.sum_light_area = sc->sum_light_area;
+    S.sum_light_power = sc->sum_light_power;
+    S.cam_x = sc->cam_pos[0];
+    S.cam_y = sc->cam_pos[1];
+    S.cam_z = sc->cam_pos[2];
+    S.cam_scale = sc->cam_scale;
+    S.aspect = sc->width / (float)sc->height;  // Renderer.cpp:21
+    S.width = sc->width;
+    S.height = sc->height;
+    S.seed = seed;
+    const uint64_t f4 = 2ull * nn + 4ull * nt;
+    S.lds_float4s = (f4 * 16ull <= kLdsLimit) ? (uint32_t)f4 : 0u;
+    ctx->has_scene = true;
+    return HPT_OK;
+}
+
+int hpt_set_seed(hpt_ctx* ctx, uint32_t seed) {
+    if (!ctx) return fail(HPT_ERR_INVALID_ARGUMENT, "ctx is null");
+    ctx->S.seed = seed;
+    return HPT_OK;
+}
+
+int hpt_set_wavefront_capacity(hpt_ctx* ctx, uint64_t paths) {
+    if (!ctx) return fail(HPT_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (paths < 64 || paths > (1ull << 31)) return fail(HPT_ERR_INVALID_ARGUMENT, "wavefront capacity must be in [64, 2^31]");
+    ctx->wf_capacity = paths & ~63ull;
+    return HPT_OK;
+}
+
+int hpt_accum_buffer(hpt_ctx* ctx, int64_t** accum_dev, size_t* num_elements) {
+    if (!ctx || !ctx->has_scene) return fail(HPT_ERR_NO_SCENE, "no scene uploaded");
+    if (accum_dev) *accum_dev = ctx->d_accum;
+    if (num_elements) *num_elements = ctx->accum_elems;
+    return HPT_OK;
+}
+
+int hpt_accum_clear(hpt_ctx* ctx, int64_t* accum_dev, void* stream) {
+    if (!ctx || !ctx->has_scene) return fail(HPT_ERR_NO_SCENE, "no scene uploaded");
+    if (int rc = set_device(ctx)) return rc;
+    HIP_TRY(hipMemsetAsync(accum_dev ? accum_dev : ctx->d_accum, 0, ctx->accum_elems * sizeof(int64_t), (hipStream_t)stream));
+    return HPT_OK;
+}
+
+int hpt_render(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sample_begin, uint32_t sample_count,
+               int64_t* accum_dev, void* stream_) {
+    if (!ctx || !ctx->has_scene) return fail(HPT_ERR_NO_SCENE, "no scene uploaded");
+    if (mode != HPT_MODE_SINGLE_KERNEL && mode != HPT_MODE_STREAMED) return fail(HPT_ERR_INVALID_ARGUMENT, "mode must be 1 or 2, got %d", mode);
+    if (block < 1 || block > 1024) return fail(HPT_ERR_INVALID_ARGUMENT, "block size %d not in [1, 1024]", block);
+    if (max_depth < 0 || max_depth > (1 << 20)) return fail(HPT_ERR_INVALID_ARGUMENT, "bad max_depth %d", max_depth);
+    if ((uint64_t)sample_begin + sample_count > 0xFFFFFFFFull) return fail(HPT_ERR_INVALID_ARGUMENT, "sample range overflows 32 bits");
+    if (int rc = set_device(ctx)) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    int64_t* accum = accum_dev ? accum_dev : ctx->d_accum;
+    if (sample_count == 0 || max_depth == 0) return HPT_OK;  // castRay's loop body never runs: radiance 0
+    const DevScene& S = ctx->S;
+    const uint32_t tiles = (((uint32_t)S.width + 7u) >> 3) * (((uint32_t)S.height + 7u) >> 3);
+    const uint64_t lanes = (uint64_t)tiles * 64ull;  // lanes per sample (edge tiles are partly idle)
+    const uint32_t lds = lds_bytes(S);
+
+    hipEvent_t ev0 = take_event(ctx), ev1 = take_event(ctx);
+    HIP_TRY(hipEventRecord(ev0, stream));
+    uint32_t launches = 0;
+
+    if (mode == HPT_MODE_SINGLE_KERNEL) {
+        const uint64_t blocks = (lanes + (uint64_t)block - 1) / (uint64_t)block;
+        if (blocks > 0x7FFFFFFFull) return fail(HPT_ERR_INVALID_ARGUMENT, "image too large for block size %d", block);
+        for (uint32_t s = sample_begin; s < sample_begin + sample_count;) {
+            const uint32_t e = (sample_begin + sample_count - s > ctx->spp_per_launch) ? s + ctx->spp_per_launch : sample_begin + sample_count;
+            if (lds) {
+                if (block <= 256) hipLaunchKernelGGL((k_render_mega<true, 256>), dim3((uint32_t)blocks), dim3(block), lds, stream, S, max_depth, s, e, accum, ctx->d_stats);
+                else hipLaunchKernelGGL((k_render_mega<true, 1024>), dim3((uint32_t)blocks), dim3(block), lds, stream, S, max_depth, s, e, accum, ctx->d_stats);
+            } else {
+                if (block <= 256) hipLaunchKernelGGL((k_render_mega<false, 256>), dim3((uint32_t)blocks), dim3(block), 0, stream, S, max_depth, s, e, accum, ctx->d_stats);
+                else hipLaunchKernelGGL((k_render_mega<false, 1024>), dim3((uint32_t)blocks), dim3(block), 0, stream, S, max_depth, s, e, accum, ctx->d_stats);
+            }
+            HIP_TRY(hipGetLastError());
+            ++launches;
+            s = e;
+        }
+    } else {
+        // the wavefront kernels are built for workgroups of up to 256 lanes
+        const int wblock = block > 256 ? 256 : block;
+        const uint64_t total = lanes * (uint64_t)sample_count;
+        const uint64_t cap = ctx->wf_capacity < total ? ctx->wf_capacity : ((total + 63ull) & ~63ull);
+        if (int rc = ensure_wavefront(ctx, cap, max_depth)) return rc;
+        WfQueue q[2] = {{ctx->d_wf[0], ctx->d_wf[1], ctx->d_wf[2], ctx->d_wf[3]}, {ctx->d_wf[4], ctx->d_wf[5], ctx->d_wf[6], ctx->d_wf[7]}};
+        for (uint64_t first = 0; first < total; first += cap) {
+            const uint32_t count = (uint32_t)((total - first < cap) ? total - first : cap);
+            const int grid = grid_for(ctx, count, wblock);
+            HIP_TRY(hipMemsetAsync(ctx->d_live, 0, (size_t)(max_depth + 1) * sizeof(uint32_t), stream));
+            hipLaunchKernelGGL(k_wf_generate, dim3(grid), dim3(wblock), 0, stream, S, sample_begin, first, count, (uint32_t)lanes, q[0], ctx->d_live, ctx->d_stats);
+            HIP_TRY(hipGetLastError());
+            ++launches;
+            for (int it = 0; it < max_depth; ++it) {
+                const WfQueue& qi = q[it & 1];
+                const WfQueue& qo = q[(it + 1) & 1];
+                if (lds) {
+                    hipLaunchKernelGGL((k_wf_extend<true>), dim3(grid), dim3(wblock), lds, stream, S, qi, ctx->d_live + it, ctx->d_hits, ctx->d_stats);
+                    hipLaunchKernelGGL((k_wf_shade<true>), dim3(grid), dim3(wblock), lds, stream, S, max_depth, qi, ctx->d_hits, ctx->d_live + it, qo, ctx->d_live + it + 1, accum, ctx->d_stats);
+                } else {
+                    hipLaunchKernelGGL((k_wf_extend<false>), dim3(grid), dim3(wblock), 0, stream, S, qi, ctx->d_live + it, ctx->d_hits, ctx->d_stats);
+                    hipLaunchKernelGGL((k_wf_shade<false>), dim3(grid), dim3(wblock), 0, stream, S, max_depth, qi, ctx->d_hits, ctx->d_live + it, qo, ctx->d_live + it + 1, accum, ctx->d_stats);
+                }
+                HIP_TRY(hipGetLastError());
+                launches += 2;
+            }
+        }
+    }
+    HIP_TRY(hipEventRecord(ev1, stream));
+    ctx->pending_events.emplace_back(ev0, ev1);
+    ctx->launches += launches;
+    return HPT_OK;
+}
+
+int hpt_resolve_dev(hpt_ctx* ctx, const int64_t* accum_dev, uint32_t spp_total, float* rgb_dev, void* stream) {
+    if (!ctx || !ctx->has_scene) return fail(HPT_ERR_NO_SCENE, "no scene uploaded");
+    if (!rgb_dev) return fail(HPT_ERR_INVALID_ARGUMENT, "rgb_dev is null");
+    if (spp_total == 0) return fail(HPT_ERR_INVALID_ARGUMENT, "spp_total is 0");
+    if (int rc = set_device(ctx)) return rc;
+    const size_t n = ctx->accum_elems;
+    const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(256), 0, (hipStream_t)stream, accum_dev ? accum_dev : ctx->d_accum, n,
+                       16777216.0 * (double)spp_total, rgb_dev);
+    HIP_TRY(hipGetLastError());
+    return HPT_OK;
+}
+
+int hpt_resolve(hpt_ctx* ctx, const int64_t* accum_dev, uint32_t spp_total, float* rgb_host, void* stream) {
+    if (!rgb_host) return fail(HPT_ERR_INVALID_ARGUMENT, "rgb_host is null");
+    if (int rc = hpt_resolve_dev(ctx, accum_dev, spp_total, ctx ? ctx->d_rgb : nullptr, stream)) return rc;
+    HIP_TRY(hipMemcpyAsync(rgb_host, ctx->d_rgb, ctx->accum_elems * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return HPT_OK;
+}
+
+int hpt_intersect_batch_dev(hpt_ctx* ctx, size_t n, const float* o_dev, const float* d_dev, const uint8_t* shadow_dev,
+                            const double* tmax_dev, int32_t* prim_dev, double* t_dev, int block, void* stream) {
+    if (!ctx || !ctx->has_scene) return fail(HPT_ERR_NO_SCENE, "no scene uploaded");
+    if (n == 0) return HPT_OK;
+    if (!o_dev || !d_dev || !prim_dev || !t_dev) return fail(HPT_ERR_INVALID_ARGUMENT, "null ray/result pointer");
+    if (shadow_dev && !tmax_dev) return fail(HPT_ERR_INVALID_ARGUMENT, "shadow flags given without tmax");
+    if (block < 1 || block > 1024) return fail(HPT_ERR_INVALID_ARGUMENT, "block size %d not in [1, 1024]", block);
+    if (int rc = set_device(ctx)) return rc;
+    const DevScene& S = ctx->S;
+    const uint32_t lds = lds_bytes(S);
+    const int grid = grid_for(ctx, n, block);
+    if (lds) hipLaunchKernelGGL((k_intersect_batch<true>), dim3(grid), dim3(block), lds, (hipStream_t)stream, S, n, o_dev, d_dev, shadow_dev, tmax_dev, prim_dev, t_dev);
+    else hipLaunchKernelGGL((k_intersect_batch<false>), dim3(grid), dim3(block), 0, (hipStream_t)stream, S, n, o_dev, d_dev, shadow_dev, tmax_dev, prim_dev, t_dev);
+    HIP_TRY(hipGetLastError());
+    return HPT_OK;
+}
+
+int hpt_intersect_batch(hpt_ctx* ctx, size_t n, const float* o, const float* d, const uint8_t* shadow, const double* tmax,
+                        int32_t* prim, double* t) {
+    if (!ctx || !ctx->has_scene) return fail(HPT_ERR_NO_SCENE, "no scene uploaded");
+    if (n == 0) return HPT_OK;
+    if (!o || !d || !prim || !t) return fail(HPT_ERR_INVALID_ARGUMENT, "null ray/result pointer");
+    if (shadow && !tmax) return fail(HPT_ERR_INVALID_ARGUMENT, "shadow flags given without tmax");
+    if (int rc = set_device(ctx)) return rc;
+    float *d_o = nullptr, *d_d = nullptr;
+    uint8_t* d_s = nullptr;
+    double *d_tm = nullptr, *d_t = nullptr;
+    int32_t* d_p = nullptr;
+    int rc = HPT_OK;
+    auto cleanup = [&]() {
+        (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_s); (void)hipFree(d_tm); (void)hipFree(d_t); (void)hipFree(d_p);
+    };
+#define TRY_OR_CLEAN(expr)                                                                              \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) { cleanup(); return fail(HPT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } \
+    } while (0)
+    TRY_OR_CLEAN(hipMalloc((void**)&d_o, n * 12));
+    TRY_OR_CLEAN(hipMalloc((void**)&d_d, n * 12));
+    TRY_OR_CLEAN(hipMalloc((void**)&d_p, n * 4));
+    TRY_OR_CLEAN(hipMalloc((void**)&d_t, n * 8));
+    TRY_OR_CLEAN(hipMemcpy(d_o, o, n * 12, hipMemcpyHostToDevice));
+    TRY_OR_CLEAN(hipMemcpy(d_d, d, n * 12, hipMemcpyHostToDevice));
+    if (shadow) {
+        TRY_OR_CLEAN(hipMalloc((void**)&d_s, n));
+        TRY_OR_CLEAN(hipMalloc((void**)&d_tm, n * 8));
+        TRY_OR_CLEAN(hipMemcpy(d_s, shadow, n, hipMemcpyHostToDevice));
+        TRY_OR_CLEAN(hipMemcpy(d_tm, tmax, n * 8, hipMemcpyHostToDevice));
+    }
+    rc = hpt_intersect_batch_dev(ctx, n, d_o, d_d, d_s, d_tm, d_p, d_t, 256, nullptr);
+    if (rc == HPT_OK) {
+        TRY_OR_CLEAN(hipDeviceSynchronize());
+        TRY_OR_CLEAN(hipMemcpy(prim, d_p, n * 4, hipMemcpyDeviceToHost));
+        TRY_OR_CLEAN(hipMemcpy(t, d_t, n * 8, hipMemcpyDeviceToHost));
+    }
+#undef TRY_OR_CLEAN
+    cleanup();
+    return rc;
+}
+
+int hpt_stats_get(hpt_ctx* ctx, hpt_stats* out) {
+    if (!ctx || !out) return fail(HPT_ERR_INVALID_ARGUMENT, "null argument");
+    if (int rc = set_device(ctx)) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    if (int rc = settle_events(ctx)) return rc;
+    unsigned long long h[kNumStats];
+    HIP_TRY(hipMemcpy(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost));
+    std::memset(out, 0, sizeof *out);
+    out->closest_queries = h[kStatClosest];
+    out->shadow_queries = h[kStatShadow];
+    out->paths = h[kStatPaths];
+    out->kernel_ms = ctx->kernel_ms;
+    out->launches = ctx->launches;
+    return HPT_OK;
+}
+
+int hpt_stats_reset(hpt_ctx* ctx) {
+    if (!ctx) return fail(HPT_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (int rc = set_device(ctx)) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    if (int rc = settle_events(ctx)) return rc;
+    HIP_TRY(hipMemset(ctx->d_stats, 0, kNumStats * sizeof(unsigned long long)));
+    ctx->kernel_ms = 0.0;
+    ctx->launches = 0;
+    return HPT_OK;
+}
+
+}  // extern "C"

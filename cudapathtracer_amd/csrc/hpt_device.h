@@ -1,0 +1,519 @@
+// Device-side building blocks of the gfx950 path-tracing core: vector math in
+// the reference's (glm) operation order, the keyed Philox stream, the portable
+// sin/cos/acos, the threaded BVH walk over the flattened node/triangle records
+// and one bounce of the MIS integrator.
+//
+// Arithmetic contract: this translation unit is compiled with
+// -ffp-contract=off; every float/double operation below is a single IEEE-754
+// operation in a fixed order, divisions and square roots are correctly
+// rounded.  Results therefore do not depend on the compiler's scheduling and
+// can be compared bit for bit with a CPU evaluation of the same expressions.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/hpt.h"
+
+namespace hpt {
+
+// ---------------------------------------------------------------- vec3 ------
+// glm::vec3 semantics (external/glm/detail/func_geometric.inl:54-96):
+// dot = (x*x' + y*y') + z*z', cross as written there, normalize = v * (1/sqrt(dot)).
+struct f3 {
+    float x, y, z;
+};
+#define HD __device__ __forceinline__
+HD f3 mk(float a, float b, float c) { return f3{a, b, c}; }
+HD f3 mk(float a) { return f3{a, a, a}; }
+HD f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+HD f3 operator-(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+HD f3 operator-(f3 a) { return mk(-a.x, -a.y, -a.z); }
+HD f3 operator*(f3 a, f3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+HD f3 operator*(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+HD f3 operator*(float s, f3 a) { return mk(s * a.x, s * a.y, s * a.z); }
+HD f3 operator/(f3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
+HD float dot(f3 a, f3 b) {
+    float tx = a.x * b.x, ty = a.y * b.y, tz = a.z * b.z;
+    return tx + ty + tz;
+}
+HD f3 cross(f3 x, f3 y) { return mk(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y); }
+HD float length(f3 v) { return sqrtf(dot(v, v)); }
+HD f3 normalize(f3 v) { return v * (1.0f / sqrtf(dot(v, v))); }
+HD float gmax(float x, float y) { return (x < y) ? y : x; }  // glm::max
+HD f3 xyz(float4 v) { return mk(v.x, v.y, v.z); }
+
+// common/MathUtils.hpp:64-74
+constexpr float kPi = 3.1415926535897932384626422832795028841971f;
+constexpr float kEpsilon5 = 1e-5f;
+constexpr float kEpsilon4 = (5 * 1e-4f);
+constexpr float kInfinity = 1e30f;
+
+// ------------------------------------------------------------- Philox -------
+// Philox4x32-10; key = (pixel, sample), counter = (depth, block, seed, 0).
+// A path's draws are addressed, never streamed, so a sample's radiance does
+// not depend on which lane, launch or GPU computes it.
+struct u4 {
+    uint32_t x, y, z, w;
+};
+HD u4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int round = 0; round < 10; ++round) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0;
+        uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return u4{c0, c1, c2, c3};
+}
+HD float u01(uint32_t bits) { return (float)(bits >> 8) * (1.0f / 16777216.0f); }
+constexpr uint32_t kCameraDepth = 0xFFFFFFFFu;
+
+// ------------------------------------------------------- portable trig ------
+// sin/cos by quadrant reduction (3-term pi/2) + degree-7/8 polynomials, acos by
+// the asin polynomial on [0, 0.5]; about 1 ulp on the ranges used here
+// ([0, 2pi] and [0, 1]).  Written out operation by operation because the
+// sequence *is* the definition.
+HD void portable_sincos(float x, float& s_out, float& c_out) {
+    float kf = x * 0.636619772f;
+    kf = kf + 0.5f;
+    int k = (int)kf;
+    float fk = (float)k;
+    float r = x - fk * 1.5703125f;
+    r = r - fk * 4.837512969970703125e-4f;
+    r = r - fk * 7.54978995489188216e-8f;
+    float s = r * r;
+    float sp = -1.9515295891e-4f * s;
+    sp = sp + 8.3321608736e-3f;
+    sp = sp * s;
+    sp = sp - 1.6666654611e-1f;
+    sp = sp * s;
+    sp = sp * r;
+    sp = sp + r;
+    float cp = 2.443315711809948e-5f * s;
+    cp = cp - 1.388731625493765e-3f;
+    cp = cp * s;
+    cp = cp + 4.166664568298827e-2f;
+    cp = cp * s;
+    cp = cp * s;
+    float hs = 0.5f * s;
+    cp = cp - hs;
+    cp = cp + 1.0f;
+    int q = k & 3;
+    float sv = (q & 1) ? cp : sp;
+    float cv = (q & 1) ? sp : cp;
+    s_out = (q & 2) ? -sv : sv;
+    c_out = (q == 1 || q == 2) ? -cv : cv;
+}
+HD float portable_asin_poly(float a, float z) {
+    float p = 4.2163199048e-2f * z;
+    p = p + 2.4181311049e-2f;
+    p = p * z;
+    p = p + 4.5470025998e-2f;
+    p = p * z;
+    p = p + 7.4953002686e-2f;
+    p = p * z;
+    p = p + 1.6666752422e-1f;
+    p = p * z;
+    p = p * a;
+    p = p + a;
+    return p;
+}
+HD float portable_acos(float x) {
+    if (x > 0.5f) {
+        float z = 0.5f * (1.0f - x);
+        float s = sqrtf(z);
+        return 2.0f * portable_asin_poly(s, z);
+    }
+    if (x < -0.5f) {
+        float z = 0.5f * (1.0f + x);
+        float s = sqrtf(z);
+        return kPi - 2.0f * portable_asin_poly(s, z);
+    }
+    return 1.5707963267948966f - portable_asin_poly(x, x * x);
+}
+
+// ------------------------------------------------- fixed-point radiance -----
+HD long long radiance_to_fixed(float v) {
+    double x = (double)v;
+    if (!(x == x)) return 0;
+    if (x > 1048576.0) x = 1048576.0;
+    if (x < -1048576.0) x = -1048576.0;
+    return (long long)__builtin_rint(x * 16777216.0);
+}
+
+// ---------------------------------------------------------------- scene -----
+struct DevScene {
+    const float4* nodes;      // 2 x float4 per node: (pMin, miss link) (pMax, triangle | -1)
+    const float* node_area;
+    const float4* tris;       // 4 x float4 per triangle
+    const float4* tri_v12;    // 2 x float4 per triangle
+    const hpt_material* mats;
+    const hpt_light* lights;
+    uint32_t num_nodes, num_tris, num_mats, num_lights;
+    float sum_light_area, sum_light_power;
+    float cam_x, cam_y, cam_z, cam_scale, aspect;
+    int width, height;
+    uint32_t seed;
+    uint32_t lds_float4s;  // > 0: nodes+tris are staged into LDS (2*num_nodes + 4*num_tris float4)
+};
+
+// Stage the node and triangle records into LDS (tiny scenes: the Cornell box is
+// 63 nodes + 32 triangles = 4 KiB).  Every thread of the workgroup must call it.
+HD void stage_scene_lds(const DevScene& S, float4* lds) {
+    const uint32_t nn = 2u * S.num_nodes, nt = 4u * S.num_tris;
+    for (uint32_t i = threadIdx.x; i < nn; i += blockDim.x) lds[i] = S.nodes[i];
+    for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) lds[nn + i] = S.tris[i];
+    __syncthreads();
+}
+
+// ------------------------------------------------------------ traversal -----
+// BVHAccel::getIntersection (common/BVH.hpp:91-145) over the flattened tree:
+//   node visited after a box hit  = i + 1        (nextIfHit  = pre-order successor, BVH.cpp:53-62)
+//   node visited after a box miss = miss link    (nextIfMiss, BVH.cpp:22-37)
+// with Bounds3::IntersectP (common/Bounds3.hpp:93-118: float slab test, no
+// t-range culling, NaN comparisons false) and Triangle::getIntersection
+// (common/Triangle.hpp:164-198: float cross/dot products, double det, 1/det,
+// u, v, t).  Closest hit keeps the strict `<` update in visit order
+// (BVH.hpp:130); triangles are stored in visit order, so no tie-break is needed.
+// kShadow: any-hit with t < tmax - Epsilon4 (BVH.hpp:121-127); returns on the first.
+template <bool kLds, bool kShadow>
+HD void trace(const DevScene& S, const float4* __restrict__ lds, f3 o, f3 d, double tmax, int& hit_tri, double& hit_t) {
+    const float4* N;
+    const float4* T;
+    if constexpr (kLds) {
+        N = lds;
+        T = lds + 2u * S.num_nodes;
+    } else {
+        N = S.nodes;
+        T = S.tris;
+    }
+    const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // == float(1. / double(d)), Ray.hpp:21
+    const bool nx = d.x < 0, ny = d.y < 0, nz = d.z < 0;
+    const double limit = tmax - (double)kEpsilon4;
+    int best = -1;
+    double best_t = (double)kInfinity;
+    int node = 0;
+    const int end = (int)S.num_nodes;
+    while (node < end) {
+        const float4 lo = N[2 * node], hi = N[2 * node + 1];
+        const float ax = (lo.x - o.x) * inv.x, bx = (hi.x - o.x) * inv.x;
+        const float ay = (lo.y - o.y) * inv.y, by = (hi.y - o.y) * inv.y;
+        const float az = (lo.z - o.z) * inv.z, bz = (hi.z - o.z) * inv.z;
+        float tMin = nx ? bx : ax, tMax = nx ? ax : bx;
+        const float tyMin = ny ? by : ay, tyMax = ny ? ay : by;
+        const float tzMin = nz ? bz : az, tzMax = nz ? az : bz;
+        bool hit = !((tMin > tyMax) || (tyMin > tMax));
+        if (tyMin > tMin) tMin = tyMin;
+        if (tyMax < tMax) tMax = tyMax;
+        hit = hit && !((tMin > tzMax) || (tzMin > tMax));
+        int next = __float_as_int(lo.w);
+        if (hit) {
+            next = node + 1;
+            const int tri = __float_as_int(hi.w);
+            if (tri >= 0) {
+                const float4 t3 = T[4 * tri + 3];
+                const f3 n = xyz(t3);
+                if (!(dot(d, n) > 0)) {
+                    const float4 t0 = T[4 * tri], t1 = T[4 * tri + 1], t2 = T[4 * tri + 2];
+                    const f3 v0 = xyz(t0), e1 = xyz(t1), e2 = xyz(t2);
+                    const f3 pvec = cross(d, e2);
+                    const float detf = dot(e1, pvec);
+                    if (!(fabsf(detf) < kEpsilon5)) {
+                        const double det_inv = 1. / (double)detf;
+                        const f3 tvec = o - v0;
+                        const double u = (double)dot(tvec, pvec) * det_inv;
+                        if (!(u < 0 || u > 1)) {
+                            const f3 qvec = cross(tvec, e1);
+                            const double v = (double)dot(d, qvec) * det_inv;
+                            if (!(v < 0 || u + v > 1)) {
+                                const double t = (double)dot(e2, qvec) * det_inv;
+                                if (!(t < 0)) {
+                                    if constexpr (kShadow) {
+                                        if (t < limit) {
+                                            best = tri;
+                                            best_t = t;
+                                            next = end;
+                                        }
+                                    } else {
+                                        if (t < best_t) {
+                                            best = tri;
+                                            best_t = t;
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        node = next;
+    }
+    hit_tri = best;
+    hit_t = best_t;
+}
+
+// -------------------------------------------------------------- shading -----
+// common/MathUtils.hpp:124-222
+HD f3 local_to_world(f3 local_dir, f3 normal) {
+    f3 t;
+    if (fabsf(normal.x) > fabsf(normal.y)) {
+        const float inv_len = 1.0f / sqrtf(normal.x * normal.x + normal.z * normal.z);
+        t = mk(normal.z * inv_len, 0.0f, -normal.x * inv_len);
+    } else {
+        const float inv_len = 1.0f / sqrtf(normal.y * normal.y + normal.z * normal.z);
+        t = mk(0.0f, normal.z * inv_len, -normal.y * inv_len);
+    }
+    const f3 b = cross(t, normal);
+    return local_dir.x * b + local_dir.y * t + local_dir.z * normal;
+}
+HD f3 sampleHemisphereCosine(f3 n, float rx, float ry) {
+    float r = sqrtf(rx);
+    float theta = ry * kPi * 2.0f;
+    float sn, cs;
+    portable_sincos(theta, sn, cs);
+    float dx = cs * r, dy = sn * r;
+    float z = sqrtf(1.f - (dx * dx + dy * dy));
+    return local_to_world(mk(dx, dy, z), n);
+}
+HD float pow5(float x) { float x2 = x * x; return x2 * x2 * x; }
+HD float lerp(float x, float y, float t) { return x * (1.0f - t) + y * t; }
+HD f3 lerp(f3 a, f3 b, float t) { return a * (1.0f - t) + b * t; }
+HD float satDot(f3 a, f3 b) { return gmax(dot(a, b), 0.f); }
+HD float absDot(f3 a, f3 b) { return fabsf(dot(a, b)); }
+HD float powerHeuristic(float f, float g) {
+    if (isinf(f)) return 1.0f;
+    float f2 = f * f;
+    return f2 / (f2 + g * g);
+}
+HD float luminance(f3 c) { return dot(c, mk(.2126f, .7152f, .0722f)); }
+
+// common/Material.hpp:48-80, :100-102
+HD float ggx_distribution(float ndm, float roughness_sq) {
+    const float ndm_sq = ndm * ndm;
+    float denominator = ndm_sq * (roughness_sq - 1.0f) + 1.0f;
+    denominator = kPi * denominator * denominator;
+    return roughness_sq / denominator;
+}
+HD float ggx_geometry(float nl, float nv, float roughness) {
+    return 2.0f / lerp(fabsf(2 * nl * nv), fabsf(nl + nv), roughness);
+}
+HD f3 reflect(f3 ray_in_dir, f3 normal) { return ray_in_dir - dot(ray_in_dir, normal) * normal * 2.f; }  // :6-8
+
+struct Mat {
+    int type;
+    f3 emission, albedo;
+    float metallic, roughness;
+};
+HD Mat load_material(const DevScene& S, int idx) {
+    const hpt_material& m = S.mats[idx];
+    Mat r;
+    r.type = m.type;
+    r.emission = mk(m.emission[0], m.emission[1], m.emission[2]);
+    r.albedo = mk(m.albedo[0], m.albedo[1], m.albedo[2]);
+    r.metallic = m.metallic;
+    r.roughness = m.roughness;
+    return r;
+}
+HD bool mat_emitting(const Mat& m) { return dot(m.emission, m.emission) > 0.0f; }  // Material.hpp:144-146
+HD bool mat_has_specular(const Mat& m) {                                              // :151-162
+    return (m.type == 1 && sqrtf(m.roughness) < 1e-3f) || m.type == 2;
+}
+// Material::pdf and Material::bsdf (Material.hpp:257-276, :315-347), Lambertian and
+// MetallicWorkflow, evaluated together because the integrator always needs both.
+HD void mat_eval(const Mat& m, f3 src, f3 out, f3 normal, f3& bsdf, float& pdf) {
+    if (m.type == 0) {
+        const bool front = dot(out, normal) > 0.0f;
+        pdf = front ? 0.5f * 1.f / kPi : 0.0f;
+        bsdf = front ? m.albedo * 1.f / kPi : mk(0.0f);
+        return;
+    }
+    const float nds = dot(normal, src), ndo = dot(normal, out);
+    const float check = nds * ndo;
+    if (check <= 0.0f) {
+        pdf = 0.0f;
+        bsdf = mk(0.0f);
+        return;
+    }
+    const f3 mm = normalize(src + out);
+    const float ndm = dot(normal, mm);
+    const float mdo = dot(mm, out);
+    const float rsq = m.roughness * m.roughness;
+    const float andm = fabsf(ndm);
+    const float jac = mdo == 0.0f ? 0.0f : 1.0f / (4 * fabsf(mdo));
+    pdf = (ggx_distribution(andm, rsq) * andm) * jac;
+    const float D = ggx_distribution(ndm, rsq);
+    const float G = ggx_geometry(nds, ndo, m.roughness);
+    const f3 f0 = lerp(mk(0.04f), m.albedo, m.metallic);
+    const f3 F = f0 + (mk(1.0f) - f0) * pow5(1.0f - mdo);
+    const f3 kd = (mk(1.0f) - F) * (1.0f - m.metallic);
+    const f3 diffuse = kd * m.albedo * 1.f / kPi;
+    const f3 specular = D * F * G / 4.0f;
+    bsdf = diffuse + specular;
+}
+// Material::sample (Material.hpp:186-199); r0/r1 are draws kSlotBsdf0/1
+HD f3 mat_sample(const Mat& m, float r0, float r1, f3 ray_out_dir, f3 normal) {
+    if (m.type == 0) return sampleHemisphereCosine(normal, r0, r1);
+    const float rsq = m.roughness * m.roughness;
+    const float theta = portable_acos(sqrtf((1.0f - r0) / ((rsq - 1.0f) * r0 + 1.0f)));
+    const float phi = 2 * kPi * r1;
+    float st, ct, sp, cp;
+    portable_sincos(theta, st, ct);
+    portable_sincos(phi, sp, cp);
+    const f3 micro = local_to_world(mk(st * cp, st * sp, ct), normal);
+    return reflect(-ray_out_dir, micro);
+}
+
+// Per-path state carried between bounces (PathSegment, common/Ray.hpp:36-52,
+// minus the RNG state, which the keyed stream makes unnecessary).
+struct Path {
+    f3 o, d;          // current ray
+    f3 thr, rad;      // throughput, accumulated radiance
+    float pdf;        // bsdfSamplePdf of the previous bounce
+    int depth;        // bounces done so far (== loop index of Scene::castRay)
+    bool specular;    // specularBounce
+    uint32_t pixel, sample;
+};
+
+// Renderer.cpp:32-39 / CudaPathTrace.cu:39-59: jittered primary ray (one jitter
+// value for both axes), throughput 1, radiance 0.
+HD void generate_camera_path(const DevScene& S, uint32_t pixel, uint32_t sample, Path& p) {
+    const uint32_t i = pixel % (uint32_t)S.width, j = pixel / (uint32_t)S.width;
+    const u4 r = philox4x32_10(kCameraDepth, 0u, S.seed, 0u, pixel, sample);
+    const float bias = u01(r.x);
+    const float x = (2 * ((float)i + bias) / (float)S.width - 1) * S.aspect * S.cam_scale;
+    const float y = (1 - 2 * ((float)j + bias) / (float)S.height) * S.cam_scale;
+    p.o = mk(S.cam_x, S.cam_y, S.cam_z);
+    p.d = normalize(mk(-x, y, 1));
+    p.thr = mk(1.0f);
+    p.rad = mk(0.0f);
+    p.pdf = 0.0f;
+    p.depth = 0;
+    p.specular = false;
+    p.pixel = pixel;
+    p.sample = sample;
+}
+
+// Scene::TracePath (common/Scene.hpp:122-272) for a path whose closest hit is
+// (hit_tri, hit_t); hit_tri < 0 = miss.  Returns false when the path ends on
+// this bounce for the reason "missed the scene" (remainingBounces = 0, :156-161);
+// the caller ends it after max_depth bounces otherwise.  Counts shadow queries.
+template <bool kLds>
+HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, Path& p, int hit_tri, double hit_t,
+                     uint32_t& shadow_queries) {
+    bool alive = true;
+    do {
+        if (hit_tri < 0) {
+            alive = false;
+            break;
+        }
+        const float4* T = kLds ? lds + 2u * S.num_nodes : S.tris;
+        const float4 t0 = T[4 * hit_tri], t1 = T[4 * hit_tri + 1], t3 = T[4 * hit_tri + 3];
+        const f3 normal = xyz(t3);
+        const float triangleArea = t0.w;
+        const Mat material = load_material(S, __float_as_int(t1.w));
+        const f3 coords = p.o + p.d * (float)hit_t;  // Ray::operator(), Ray.hpp:27
+
+        if (mat_emitting(material)) {  // :164-184
+            if (p.depth == 0 || p.specular) {
+                p.rad = p.rad + p.thr * material.emission;
+            } else {
+                const f3 radiance = material.emission;
+                const float lightPdf = luminance(radiance) * 2.f * kPi * triangleArea / S.sum_light_power;
+                const float weight = powerHeuristic(p.pdf, lightPdf);
+                p.rad = p.rad + p.thr * radiance * weight;
+            }
+        }
+
+        const u4 ra = philox4x32_10((uint32_t)p.depth, 0u, S.seed, 0u, p.pixel, p.sample);
+        const u4 rb = philox4x32_10((uint32_t)p.depth, 1u, S.seed, 0u, p.pixel, p.sample);
+
+        if (!p.specular) {  // :192-228
+            // Scene::sampleLight (:99-120)
+            float lightSamplePdf = 0.0f;
+            f3 lx = mk(0.f), ln = mk(0.f), lemit = mk(0.f);
+            float larea = 0.f;
+            {
+                const float pick = u01(ra.x) * S.sum_light_area;
+                float emit_area_sum = 0;
+                for (uint32_t k = 0; k < S.num_lights; ++k) {
+                    const hpt_light L = S.lights[k];
+                    emit_area_sum += L.area;
+                    if (pick <= emit_area_sum) {
+                        // BVHAccel::Sample / getSample (BVH.hpp:147-184)
+                        float q = sqrtf(u01(ra.y)) * L.root_area;
+                        uint32_t node = L.root_node;
+                        int tri;
+                        while ((tri = __float_as_int(S.nodes[2 * node + 1].w)) < 0) {
+                            const uint32_t left = node + 1;
+                            const float la = S.node_area[left];
+                            if (q < la) node = left;
+                            else {
+                                q -= la;
+                                node = (uint32_t)__float_as_int(S.nodes[2 * left].w);
+                            }
+                        }
+                        // Triangle::Sample (Triangle.hpp:75-82)
+                        const float sx = sqrtf(u01(ra.z)), sy = u01(ra.w);
+                        const float4 a0 = S.tris[4 * tri], a3 = S.tris[4 * tri + 3];
+                        const float4 b1 = S.tri_v12[2 * tri], b2 = S.tri_v12[2 * tri + 1];
+                        lx = xyz(a0) * (1.0f - sx) + xyz(b1) * (sx * (1.0f - sy)) + xyz(b2) * (sx * sy);
+                        ln = xyz(a3);
+                        larea = a0.w;
+                        lightSamplePdf = 1.0f / L.root_area;
+                        const hpt_material& lm = S.mats[L.material];
+                        lemit = mk(lm.emission[0], lm.emission[1], lm.emission[2]);
+                        break;
+                    }
+                }
+            }
+            if (lightSamplePdf > 0.0f) {
+                const f3 wo = -p.d;
+                const f3 px = lx - coords;
+                const f3 wi = normalize(px);
+                const f3 so = coords + wi * kEpsilon5;
+                int occ_tri;
+                double occ_t;
+                ++shadow_queries;
+                trace<kLds, true>(S, lds, so, wi, (double)length(px), occ_tri, occ_t);
+                if (occ_tri < 0) {
+                    f3 bsdf;
+                    float bsdfPdf;
+                    mat_eval(material, wi, wo, normal, bsdf, bsdfPdf);
+                    const float cos_theta = satDot(normal, wi);
+                    const float cos_theta_prime = satDot(ln, -wi);
+                    const float r2 = dot(lx - coords, lx - coords);
+                    const float lightPdf = luminance(lemit) * 2.f * kPi * larea / S.sum_light_power;
+                    const float weight = powerHeuristic(lightPdf, bsdfPdf);
+                    p.rad = p.rad + p.thr * lemit * bsdf * cos_theta * cos_theta_prime / r2 / lightSamplePdf * weight;
+                }
+            }
+        }
+
+        // :230-250
+        const f3 wo = -p.d;
+        const f3 wi = mat_sample(material, u01(rb.x), u01(rb.y), wo, normal);
+        f3 bsdf;
+        float pdf;
+        mat_eval(material, wi, wo, normal, bsdf, pdf);
+        p.pdf = pdf;
+        if (pdf < kEpsilon5) break;  // the path keeps its ray and re-traces it (:238-240)
+        p.specular = mat_has_specular(material);
+        const float cos_theta = absDot(normal, wi);
+        p.thr = p.thr * (bsdf * cos_theta / pdf);
+        p.o = coords + wi * kEpsilon5;
+        p.d = wi;
+    } while (false);
+
+    p.depth++;  // :268-271
+    if (isnan(p.rad.x) || isnan(p.rad.y) || isnan(p.rad.z) || isinf(p.rad.x) || isinf(p.rad.y) || isinf(p.rad.z))
+        p.rad = mk(0.0f);
+    return alive;
+}
+
+#undef HD
+}  // namespace hpt

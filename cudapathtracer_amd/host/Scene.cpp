@@ -1,0 +1,210 @@
+#include "Scene.hpp"
+
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+
+void AlignedFloats::resize(size_t n) {
+    storage.assign(n + 16, 0.f);
+    uintptr_t p = reinterpret_cast<uintptr_t>(storage.data());
+    p = (p + 63u) & ~uintptr_t(63);
+    data = reinterpret_cast<float*>(p);
+    size = n;
+}
+
+namespace {
+float luminance(Vec3 c) { return dot(c, Vec3(.2126f, .7152f, .0722f)); }
+void put_int(float* dst, int32_t v) { std::memcpy(dst, &v, 4); }
+}  // namespace
+
+// light bookkeeping as common/Scene.hpp:47-56
+void Scene::Add(MeshTriangle* mesh) {
+    mesh_owner_.emplace_back(mesh);
+    meshes.push_back(mesh);
+    num_meshes = (int)meshes.size();
+    if (mesh->material.emitting()) {
+        sumLightArea += mesh->area;
+        sumLightPower += mesh->area * luminance(mesh->material._emission) * 2.f * 3.14159265358979323846264338327950288f;
+        ++num_lights;
+    }
+}
+
+float Scene::cameraScale() const {
+    const float half_deg = (float)(fov * 0.5);
+    const float half_rad = (float)(half_deg * 3.1415926535897932384626422832795028841971f / 180.0);
+    return (float)std::tan((double)half_rad);
+}
+
+// Builds the two-level BVH (top level over meshes, one nested BVH per mesh,
+// common/Scene.cpp:9-23 + common/BVH.cpp:92-104) and flattens it: every
+// top-level leaf is replaced by its mesh's subtree, whose exits continue at the
+// node that follows the leaf.
+void Scene::buildBVH() {
+    if (meshes.empty()) throw std::runtime_error("Scene::buildBVH: scene has no meshes");
+    std::vector<Object*> objects(meshes.begin(), meshes.end());
+    bvh_owner_ = std::make_shared<BVHAccel>(objects, 1, BVHAccel::SplitMethod::NAIVE);
+    bvh = bvh_owner_.get();
+    mesh_bvh_owner_.clear();
+    mesh_bvhs.clear();
+    std::vector<int32_t> mesh_base(meshes.size());
+    int32_t base = 0;
+    for (size_t k = 0; k < meshes.size(); ++k) {
+        MeshTriangle* m = meshes[k];
+        std::vector<Object*> tris(m->triangles.size());
+        for (size_t i = 0; i < tris.size(); ++i) tris[i] = &m->triangles[i];
+        mesh_bvh_owner_.push_back(std::make_shared<BVHAccel>(tris, 1, BVHAccel::SplitMethod::NAIVE));
+        mesh_bvhs.push_back(mesh_bvh_owner_.back().get());
+        mesh_base[k] = base;
+        base += m->num_triangles;
+    }
+
+    // global index of every top-level node once the mesh subtrees are spliced in
+    const std::vector<FlatNode>& top = bvh->nodes;
+    std::vector<int32_t> top_to_global(top.size() + 1);
+    int32_t cursor = 0;
+    for (size_t t = 0; t < top.size(); ++t) {
+        top_to_global[t] = cursor;
+        cursor += top[t].object >= 0 ? (int32_t)mesh_bvhs[top[t].object]->nodes.size() : 1;
+    }
+    top_to_global[top.size()] = cursor;
+    const uint32_t num_nodes = (uint32_t)cursor, num_tris = (uint32_t)base;
+
+    auto fs = std::make_shared<FlatScene>();
+    fs->num_nodes = num_nodes;
+    fs->num_tris = num_tris;
+    fs->nodes.resize(8ull * num_nodes);
+    fs->node_area.resize(num_nodes);
+    fs->tris.resize(16ull * num_tris);
+    fs->tri_v12.resize(8ull * num_tris);
+    fs->prim_of_tri.resize(num_tris);
+    fs->mesh_root.assign(meshes.size(), -1);
+
+    auto write_node = [&](int32_t g, const Bounds3& b, int32_t miss, int32_t tri, float area) {
+        float* n = fs->nodes.data + 8ull * g;
+        n[0] = b.pMin.x; n[1] = b.pMin.y; n[2] = b.pMin.z; put_int(n + 3, miss);
+        n[4] = b.pMax.x; n[5] = b.pMax.y; n[6] = b.pMax.z; put_int(n + 7, tri);
+        fs->node_area.data[g] = area;
+    };
+
+    int32_t next_tri = 0;
+    for (size_t t = 0; t < top.size(); ++t) {
+        const FlatNode& tn = top[t];
+        const int32_t g0 = top_to_global[t];
+        if (tn.object < 0) {
+            write_node(g0, tn.bounds, top_to_global[tn.miss], -1, tn.area);
+            continue;
+        }
+        const int k = tn.object;
+        const MeshTriangle* mesh = meshes[k];
+        const std::vector<FlatNode>& mn = mesh_bvhs[k]->nodes;
+        // The reference tests the mesh's bounding box (top-level leaf) and then
+        // the identical box of the nested root; one test gives the same answer.
+        const Bounds3 rb = mn[0].bounds, mb = mesh->bounding_box;
+        if (std::memcmp(&rb.pMin, &mb.pMin, sizeof(Vec3)) || std::memcmp(&rb.pMax, &mb.pMax, sizeof(Vec3)))
+            throw std::runtime_error("Scene::buildBVH: mesh bounding box differs from its BVH root (NaN or signed-zero vertex?)");
+        fs->mesh_root[k] = g0;
+        for (size_t i = 0; i < mn.size(); ++i) {
+            const FlatNode& n = mn[i];
+            int32_t tri = -1;
+            if (n.object >= 0) {
+                tri = next_tri++;
+                const Triangle& T = mesh->triangles[n.object];
+                float* r = fs->tris.data + 16ull * tri;
+                r[0] = T.v0.x; r[1] = T.v0.y; r[2] = T.v0.z; r[3] = T.area;
+                r[4] = T.e1.x; r[5] = T.e1.y; r[6] = T.e1.z; put_int(r + 7, k);
+                r[8] = T.e2.x; r[9] = T.e2.y; r[10] = T.e2.z; put_int(r + 11, mesh_base[k] + n.object);
+                r[12] = T.normal.x; r[13] = T.normal.y; r[14] = T.normal.z; put_int(r + 15, k);
+                float* w = fs->tri_v12.data + 8ull * tri;
+                w[0] = T.v1.x; w[1] = T.v1.y; w[2] = T.v1.z; w[3] = 0.f;
+                w[4] = T.v2.x; w[5] = T.v2.y; w[6] = T.v2.z; w[7] = 0.f;
+                fs->prim_of_tri[tri] = mesh_base[k] + n.object;
+            }
+            write_node(g0 + (int32_t)i, n.bounds, g0 + n.miss, tri, n.area);
+        }
+    }
+
+    for (size_t k = 0; k < meshes.size(); ++k) {
+        const Material& m = meshes[k]->material;
+        hpt_material hm;
+        std::memset(&hm, 0, sizeof hm);
+        hm.type = m.type;
+        hm.emission[0] = m._emission.x; hm.emission[1] = m._emission.y; hm.emission[2] = m._emission.z;
+        hm.albedo[0] = m._albedo.x; hm.albedo[1] = m._albedo.y; hm.albedo[2] = m._albedo.z;
+        hm.metallic = m._metallic;
+        hm.roughness = m._roughness;
+        hm.ior = m._ior;
+        fs->materials.push_back(hm);
+        if (m.emitting()) {
+            hpt_light L;
+            L.area = meshes[k]->area;
+            L.root_area = mesh_bvhs[k]->rootArea();
+            L.root_node = (uint32_t)fs->mesh_root[k];
+            L.material = (uint32_t)k;
+            fs->lights.push_back(L);
+        }
+    }
+    flat_ = fs;
+}
+
+const FlatScene& Scene::flat() const {
+    if (!flat_) throw std::runtime_error("Scene: buildBVH() has not been called");
+    return *flat_;
+}
+
+hpt_scene_desc Scene::describe() const {
+    const FlatScene& f = flat();
+    hpt_scene_desc d;
+    std::memset(&d, 0, sizeof d);
+    d.num_nodes = f.num_nodes;
+    d.nodes = f.nodes.data;
+    d.node_area = f.node_area.data;
+    d.num_tris = f.num_tris;
+    d.tris = f.tris.data;
+    d.tri_v12 = f.tri_v12.data;
+    d.num_materials = (uint32_t)f.materials.size();
+    d.materials = f.materials.data();
+    d.num_lights = (uint32_t)f.lights.size();
+    d.lights = f.lights.data();
+    d.sum_light_area = sumLightArea;
+    d.sum_light_power = sumLightPower;
+    d.cam_pos[0] = camPos.x; d.cam_pos[1] = camPos.y; d.cam_pos[2] = camPos.z;
+    d.cam_scale = cameraScale();
+    d.width = width;
+    d.height = height;
+    return d;
+}
+
+// The built-in Cornell box: resolution, camera, materials, mesh order and
+// file names of common/Scene.cpp:25-73.
+Scene Scene::CreateBuiltinScene(Scene::BuiltinScene sceneId, int maxDepth) {
+    if (sceneId != Scene::BuiltinScene::CornellBox) throw std::runtime_error("Unsupported sceneId");
+    Scene scene(512, 512);
+    scene.name = "Cornell Box";
+    scene.maxDepth = maxDepth;
+    scene.camPos = Vec3(278, 273, -800);
+
+    Material red, green, white, light, metal, glass;
+    red._albedo = Vec3(0.63f, 0.065f, 0.05f);
+    green._albedo = Vec3(0.14f, 0.45f, 0.091f);
+    white._albedo = Vec3(0.725f, 0.71f, 0.68f);
+    light._emission = (8.0f * Vec3(0.747f + 0.058f, 0.747f + 0.258f, 0.747f) + 15.6f * Vec3(0.740f + 0.287f, 0.740f + 0.160f, 0.740f) +
+                       18.4f * Vec3(0.737f + 0.642f, 0.737f + 0.159f, 0.737f));
+    metal.type = Material::Type::MetallicWorkflow;
+    metal._albedo = Vec3((float)0.7, (float)0.5, (float)0.2);
+    metal._metallic = 1.f;
+    metal._roughness = 0.005f;
+    glass.type = Material::Type::Lambertian;  // the "glass" short box is Lambertian in the reference too
+    glass._roughness = 0.2f;
+    glass._ior = 1.5f;
+
+    const char* env = std::getenv("HPT_MODELS_DIR");
+    const std::string dir = std::string(env && *env ? env : "models") + "/cornellbox/";
+    scene.Add(new MeshTriangle(dir + "floor.obj", white));
+    scene.Add(new MeshTriangle(dir + "shortbox.obj", glass));
+    scene.Add(new MeshTriangle(dir + "tallbox.obj", metal));
+    scene.Add(new MeshTriangle(dir + "left.obj", red));
+    scene.Add(new MeshTriangle(dir + "right.obj", green));
+    scene.Add(new MeshTriangle(dir + "light.obj", light));
+    scene.buildBVH();
+    return scene;
+}

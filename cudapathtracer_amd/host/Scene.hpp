@@ -1,0 +1,81 @@
+// Scene: the host-side scene description with the public members and methods
+// of the reference's Scene that callers use (common/Scene.hpp:20-93):
+// resolution, camera, maxDepth, Add(), buildBVH(), CreateBuiltinScene(), the
+// light totals.  intersect/TracePath/castRay are not host functions here: the
+// bounce loop runs on the device; buildBVH() additionally emits the flattened
+// records that hpt_scene_upload() consumes.
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/hpt.h"
+#include "BVH.hpp"
+#include "Triangle.hpp"
+
+// 64-byte aligned storage for the flattened arrays
+struct AlignedFloats {
+    std::vector<float> storage;
+    float* data = nullptr;
+    size_t size = 0;
+    void resize(size_t n);
+};
+
+// The flattened scene: one pre-order node array for the whole two-level BVH,
+// triangles in leaf order.  Record formats are documented at hpt_scene_desc.
+struct FlatScene {
+    AlignedFloats nodes, node_area, tris, tri_v12;
+    std::vector<hpt_material> materials;  // one per mesh, Scene::Add order
+    std::vector<hpt_light> lights;        // emitting meshes, Scene::Add order
+    std::vector<int32_t> prim_of_tri;     // leaf order -> global primitive id
+    std::vector<int32_t> mesh_root;       // mesh index -> node index of its BVH root
+    uint32_t num_nodes = 0, num_tris = 0;
+};
+
+class Scene {
+public:
+    // setting up options
+    std::string name = "default";
+    Vec3 camPos = Vec3(0, 0, 0);
+    int width = 1280;
+    int height = 960;
+    double fov = 40;
+    Vec3 backgroundColor = Vec3(0.235294f, 0.67451f, 0.843137f);  // unused by the integrator, as in the reference
+    int maxDepth = 1;
+    float RussianRoulette = 0.8f;  // unused (enableRR = false, common/Scene.hpp:142)
+
+    BVHAccel* bvh = nullptr;              // top level, over meshes
+    std::vector<MeshTriangle*> meshes;    // Scene::Add order
+    std::vector<BVHAccel*> mesh_bvhs;     // per mesh, same order
+    int num_meshes = 0;
+    float sumLightArea = 0.0f;
+    float sumLightPower = 0.0f;
+    int num_lights = 0;
+
+    Scene(int w, int h) : width(w), height(h) {}
+
+    // takes shared ownership of the mesh
+    void Add(MeshTriangle* mesh);
+    void buildBVH();
+
+    enum BuiltinScene {
+        CornellBox,
+    };
+    // OBJ files are opened as "models/cornellbox/<name>.obj" relative to the
+    // current directory, or under $HPT_MODELS_DIR when that is set.
+    static Scene CreateBuiltinScene(BuiltinScene sceneId, int maxDepth);
+
+    // tan(fov/2) exactly as the host renderer of the reference computes it
+    // (common/Renderer.cpp:11,20)
+    float cameraScale() const;
+
+    // valid after buildBVH(); pointers inside stay valid while the scene lives
+    const FlatScene& flat() const;
+    hpt_scene_desc describe() const;
+
+private:
+    std::vector<std::shared_ptr<MeshTriangle>> mesh_owner_;
+    std::shared_ptr<BVHAccel> bvh_owner_;
+    std::vector<std::shared_ptr<BVHAccel>> mesh_bvh_owner_;
+    std::shared_ptr<FlatScene> flat_;
+};

@@ -1,0 +1,58 @@
+// Host-side geometry: Object / Triangle / MeshTriangle with the public members
+// the reference's scene-building code uses (common/Object.hpp:12-26,
+// common/Triangle.hpp:42-59, :87-154).  Intersection and sampling run on the
+// device against the flattened records that BVHAccel/Scene emit.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "Bounds3.hpp"
+#include "Material.hpp"
+
+class Object {
+public:
+    float area = 0.f;
+    Object() {}
+    virtual ~Object() {}
+    virtual Bounds3 getBounds() const = 0;
+};
+
+class Triangle : public Object {
+public:
+    Vec3 v0, v1, v2;  // vertices, counter-clockwise
+    Vec3 e1, e2;      // v1-v0, v2-v0
+    Vec3 normal;
+    Material material;
+
+    Triangle() {}
+    // precomputation as common/Triangle.hpp:52-59
+    Triangle(Vec3 _v0, Vec3 _v1, Vec3 _v2, const Material& _m) : v0(_v0), v1(_v1), v2(_v2), material(_m) {
+        e1 = v1 - v0;
+        e2 = v2 - v0;
+        normal = normalize(cross(e1, e2));
+        area = length(cross(e1, e2)) * 0.5f;
+    }
+    Bounds3 getBounds() const override { return Union(Bounds3(v0, v1), v2); }
+};
+
+class MeshTriangle : public Object {
+public:
+    // Wavefront OBJ with `v` and triangular `f` records, one mesh per file
+    // (what common/Triangle.cpp:5-61 accepts through the vendored loader).
+    // Throws std::runtime_error if the file cannot be read or a face is not a triangle.
+    MeshTriangle(const std::string& filename, const Material& mt);
+    // triangle soup: 3 vertices per face
+    MeshTriangle(const std::vector<Vec3>& face_vertices, const Material& mt);
+
+    Bounds3 getBounds() const override { return bounding_box; }
+
+    Bounds3 bounding_box;
+    int num_vertices = 0;
+    int num_triangles = 0;
+    std::vector<Vec3> vertices;       // 3 per face, un-indexed
+    std::vector<Triangle> triangles;  // triangle soup
+    Material material;
+
+private:
+    void build(const std::vector<Vec3>& face_vertices, const Material& mt);
+};

@@ -1,0 +1,62 @@
+// gpu_path_tracer <spp> <maxDepth> <threads> <mode>
+//
+// Same positional arguments, defaults, console output and output file as the
+// reference CLI (gpu_path_tracer/main.cpp:10-58): spp 32, maxDepth 10, threads
+// per workgroup 256, mode 1 = single kernel / 2 = streamed (wavefront with
+// compaction).  Must be run from a directory that contains models/ and out/gpu/
+// (or set HPT_MODELS_DIR), like the reference.
+//
+// Optional environment knobs that default to the reference's behaviour:
+//   HPT_WIDTH / HPT_HEIGHT   resolution (the built-in scene is 512x512)
+//   HPT_DEVICE               GPU index (default 0)
+#include <cstdlib>
+#include <iostream>
+
+#include "HipRenderer.hpp"
+#include "Scene.hpp"
+#include "Utility.hpp"
+
+int main(int argc, char** argv) {
+    int spp = 32;
+    int maxDepth = 10;
+    int num_threads = 256;
+    HipRenderMode mode = HipRenderMode::SingleKernel;
+    if (argc > 1) spp = atoi(argv[1]);
+    if (argc > 2) maxDepth = atoi(argv[2]);
+    if (argc > 3) num_threads = atoi(argv[3]);
+    if (argc > 4) mode = (HipRenderMode)atoi(argv[4]);
+
+    try {
+        Scene scene = Scene::CreateBuiltinScene(Scene::CornellBox, maxDepth);
+        if (const char* w = getenv("HPT_WIDTH")) scene.width = atoi(w);
+        if (const char* h = getenv("HPT_HEIGHT")) scene.height = atoi(h);
+
+        std::cout << "Resolution: " << scene.width << "x" << scene.height << "\n";
+        std::cout << "SPP: " << spp << "\n";
+        std::cout << "Trace Depth: " << maxDepth << "\n";
+        std::cout << "HIP Mode: " << (mode == HipRenderMode::SingleKernel ? "SingleKernel" : "Streamed") << std::endl;
+        std::cout << "HIP #threads: " << num_threads << std::endl;
+
+        HipRenderer r;
+        r.spp = spp;
+        r.SetMode(mode);
+        r.num_threads = num_threads;
+        if (const char* d = getenv("HPT_DEVICE")) r.device = atoi(d);
+
+        r.PrepareRender(scene);
+        r.Render(scene);
+        const hpt_stats st = r.Stats();
+        r.FinishRender(scene);
+
+        const double rays = (double)(st.closest_queries + st.shadow_queries);
+        if (r.last_render_seconds > 0)
+            std::cout << "Rays: " << rays << " (" << rays / r.last_render_seconds * 1e-6 << " Mrays/s, " << spp / r.last_render_seconds
+                      << " spp/s)\n";
+
+        Utility::SavePPM("out/gpu/" + scene.name + ".ppm", r.framebuffer, scene.width, scene.height);
+    } catch (const std::exception& e) {
+        std::cerr << "gpu_path_tracer: " << e.what() << std::endl;
+        return 1;
+    }
+    return 0;
+}

@@ -1,0 +1,181 @@
+// C view of the C++ host classes (include/hpt_host.h).
+#include "../../include/hpt_host.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <exception>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+
+#include "HipRenderer.hpp"
+#include "Scene.hpp"
+#include "Utility.hpp"
+
+struct hpt_host_scene {
+    Scene scene;
+    explicit hpt_host_scene(const Scene& s) : scene(s) {}
+};
+
+namespace {
+thread_local std::string g_err;
+int fail(const std::string& msg) {
+    g_err = msg;
+    return 1;
+}
+Material to_material(const hpt_material* m) {
+    Material r;
+    r.type = m->type;
+    r._emission = Vec3(m->emission[0], m->emission[1], m->emission[2]);
+    r._albedo = Vec3(m->albedo[0], m->albedo[1], m->albedo[2]);
+    r._metallic = m->metallic;
+    r._roughness = m->roughness;
+    r._ior = m->ior;
+    return r;
+}
+}  // namespace
+
+#define GUARD(body)                                  \
+    try {                                            \
+        body;                                        \
+    } catch (const std::exception& e) {              \
+        return fail(e.what());                       \
+    } catch (...) {                                  \
+        return fail("unknown C++ exception");        \
+    }                                                \
+    return 0;
+
+extern "C" {
+
+const char* hpt_host_last_error(void) { return g_err.c_str(); }
+
+int hpt_host_scene_cornell(const char* models_dir, int width, int height, int max_depth, hpt_host_scene** out) {
+    if (!out) return fail("out is null");
+    *out = nullptr;
+    GUARD({
+        if (models_dir) setenv("HPT_MODELS_DIR", models_dir, 1);
+        Scene sc = Scene::CreateBuiltinScene(Scene::CornellBox, max_depth);
+        if (width > 0) sc.width = width;
+        if (height > 0) sc.height = height;
+        *out = new hpt_host_scene(sc);
+    })
+}
+
+int hpt_host_scene_create(int width, int height, const float cam_pos[3], double fov_deg, int max_depth, hpt_host_scene** out) {
+    if (!out || !cam_pos) return fail("null argument");
+    *out = nullptr;
+    GUARD({
+        Scene sc(width, height);
+        sc.camPos = Vec3(cam_pos[0], cam_pos[1], cam_pos[2]);
+        sc.fov = fov_deg;
+        sc.maxDepth = max_depth;
+        sc.name = "custom";
+        *out = new hpt_host_scene(sc);
+    })
+}
+
+int hpt_host_scene_add_obj(hpt_host_scene* s, const char* obj_path, const hpt_material* material) {
+    if (!s || !obj_path || !material) return fail("null argument");
+    GUARD(s->scene.Add(new MeshTriangle(std::string(obj_path), to_material(material))))
+}
+
+int hpt_host_scene_add_triangles(hpt_host_scene* s, const float* verts9, int num_tris, const hpt_material* material) {
+    if (!s || !verts9 || !material || num_tris <= 0) return fail("bad argument");
+    GUARD({
+        std::vector<Vec3> fv((size_t)num_tris * 3);
+        for (size_t i = 0; i < fv.size(); ++i) fv[i] = Vec3(verts9[3 * i], verts9[3 * i + 1], verts9[3 * i + 2]);
+        s->scene.Add(new MeshTriangle(fv, to_material(material)));
+    })
+}
+
+int hpt_host_scene_build(hpt_host_scene* s) {
+    if (!s) return fail("scene is null");
+    GUARD(s->scene.buildBVH())
+}
+
+int hpt_host_scene_set_resolution(hpt_host_scene* s, int width, int height) {
+    if (!s || width <= 0 || height <= 0) return fail("bad argument");
+    s->scene.width = width;
+    s->scene.height = height;
+    return 0;
+}
+
+int hpt_host_scene_destroy(hpt_host_scene* s) {
+    delete s;
+    return 0;
+}
+
+int hpt_host_scene_describe(const hpt_host_scene* s, hpt_scene_desc* out) {
+    if (!s || !out) return fail("null argument");
+    GUARD(*out = s->scene.describe())
+}
+
+int hpt_host_scene_prim_ids(const hpt_host_scene* s, int32_t* out) {
+    if (!s || !out) return fail("null argument");
+    GUARD({
+        const FlatScene& f = s->scene.flat();
+        std::memcpy(out, f.prim_of_tri.data(), f.prim_of_tri.size() * sizeof(int32_t));
+    })
+}
+
+int hpt_host_bvh_dump(const hpt_host_scene* s, int mesh, int* count, float* bounds6, int32_t* payload, float* area, int32_t* miss) {
+    if (!s || !count) return fail("null argument");
+    GUARD({
+        s->scene.flat();
+        if (mesh >= s->scene.num_meshes) throw std::runtime_error("mesh index out of range");
+        const BVHAccel* b = mesh < 0 ? s->scene.bvh : s->scene.mesh_bvhs[mesh];
+        *count = (int)b->nodes.size();
+        if (bounds6) {
+            for (size_t i = 0; i < b->nodes.size(); ++i) {
+                const FlatNode& n = b->nodes[i];
+                bounds6[6 * i + 0] = n.bounds.pMin.x; bounds6[6 * i + 1] = n.bounds.pMin.y; bounds6[6 * i + 2] = n.bounds.pMin.z;
+                bounds6[6 * i + 3] = n.bounds.pMax.x; bounds6[6 * i + 4] = n.bounds.pMax.y; bounds6[6 * i + 5] = n.bounds.pMax.z;
+                payload[i] = n.object;
+                area[i] = n.area;
+                miss[i] = n.miss;
+            }
+        }
+    })
+}
+
+int hpt_host_render(const hpt_host_scene* s, int device, int spp, int max_depth, int num_threads, int mode, float* rgb,
+                    hpt_stats* stats) {
+    if (!s || !rgb) return fail("null argument");
+    if (mode != 1 && mode != 2) return fail("mode must be 1 (SingleKernel) or 2 (Streamed)");
+    GUARD({
+        Scene sc = s->scene;
+        sc.maxDepth = max_depth;
+        HipRenderer r;
+        r.spp = spp;
+        r.device = device;
+        r.SetMode((HipRenderMode)mode);
+        r.num_threads = num_threads;
+        r.PrepareRender(sc);
+        {
+            // Render() prints the reference's timing lines; keep library calls quiet
+            std::streambuf* old = std::cout.rdbuf(nullptr);
+            try {
+                r.Render(sc);
+            } catch (...) {
+                std::cout.rdbuf(old);
+                throw;
+            }
+            std::cout.rdbuf(old);
+        }
+        if (stats) *stats = r.Stats();
+        r.FinishRender(sc);
+        std::memcpy(rgb, r.framebuffer.data(), r.framebuffer.size() * sizeof(Vec3));
+    })
+}
+
+int hpt_host_save_ppm(const char* path, const float* rgb, int width, int height) {
+    if (!path || !rgb || width <= 0 || height <= 0) return fail("bad argument");
+    GUARD({
+        std::vector<Vec3> fb((size_t)width * height);
+        std::memcpy(static_cast<void*>(fb.data()), rgb, fb.size() * sizeof(Vec3));
+        Utility::SavePPM(path, fb, width, height);
+    })
+}
+
+}  // extern "C"

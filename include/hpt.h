@@ -1,0 +1,193 @@
+/* hpt -- C ABI of the MI355X (gfx950) path-tracing core.
+ *
+ * This is the drop-in boundary: everything the reference's host code reaches
+ * through `CudaRenderer` and the CUDA_PORTABLE MallocCuda/FreeCuda deep copy is
+ * reached through these entry points instead.  Plain C types only: pointers,
+ * sizes, POD structs.  No C++ or torch types cross the boundary.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a non-zero hpt_status otherwise;
+ *    hpt_last_error() returns a thread-local message for the last failure
+ *    (the reference has no working error path: checkCUDAError is compiled
+ *    out, gpu_path_tracer/CudaUtils.h:8-19).
+ *  - one hpt_ctx per GPU; a context may be used from one host thread at a
+ *    time; there is no global mutable state (contrast the reference's
+ *    file-static host->device pointer registry, gpu_path_tracer/CudaPortable.cu:13-50).
+ *  - host arrays passed to hpt_scene_upload are borrowed for the duration of
+ *    the call only.
+ *  - `stream` arguments are hipStream_t handles passed as void* (NULL = the
+ *    default stream); device-pointer arguments are named *_dev.
+ */
+#ifndef HPT_H
+#define HPT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hpt_ctx hpt_ctx;
+
+typedef enum {
+    HPT_OK = 0,
+    HPT_ERR_INVALID_ARGUMENT = 1,
+    HPT_ERR_HIP = 2,           /* a HIP runtime call failed; see hpt_last_error() */
+    HPT_ERR_NO_SCENE = 3,      /* render/intersect before hpt_scene_upload */
+    HPT_ERR_OUT_OF_MEMORY = 4,
+    HPT_ERR_TOO_LARGE = 5      /* fixed-capacity entry point: input exceeds its limit */
+} hpt_status;
+
+/* Render modes: the values of the reference's CudaRenderMode
+ * (gpu_path_tracer/CudaRenderer.hpp:9-13) and of argv[4] of gpu_path_tracer. */
+enum { HPT_MODE_SINGLE_KERNEL = 1, HPT_MODE_STREAMED = 2 };
+
+/* Material table entry; the fields of the reference's Material
+ * (common/Material.hpp:130-142).  type: 0 Lambertian, 1 MetallicWorkflow, 2 Glass
+ * (Glass is not yet traced on the device: upload rejects it). */
+typedef struct {
+    int32_t type;
+    float emission[3];
+    float albedo[3];
+    float metallic;
+    float roughness;
+    float ior;
+    float _pad[2];
+} hpt_material; /* 48 bytes */
+
+/* One emitting mesh, in Scene::Add order (the order Scene::sampleLight walks,
+ * common/Scene.hpp:99-120). */
+typedef struct {
+    float area;         /* MeshTriangle::area: triangle areas summed in file order      */
+    float root_area;    /* mesh BVH root->area: child sums in tree order (pdf = 1/this) */
+    uint32_t root_node; /* index of the mesh's BVH root in the flattened node array     */
+    uint32_t material;
+} hpt_light;
+
+/* Flattened scene.  Replaces Scene::MallocCuda's node-by-node deep copy
+ * (gpu_path_tracer/CudaPortable.cu:157-190, :283-318).
+ *
+ * nodes: the reference's two-level BVH (common/BVH.cpp:81-168) flattened into
+ *   ONE array in pre-order, mesh BVHs spliced in at the top-level leaves.
+ *   The traversal is "threaded" like the reference's nextIfHit/nextIfMiss
+ *   links (common/BVH.cpp:53-64): after a box HIT the next node is i+1, after
+ *   a MISS it is the node's miss link; num_nodes terminates.
+ *   Record = 8 floats, 32 bytes:  pMin.xyz, bits(int32 miss link),
+ *                                 pMax.xyz, bits(int32 triangle index | -1)
+ * tris: in leaf order (= the order the reference traversal meets them; equal-t
+ *   ties resolve to the lower index, as the strict `<` of common/BVH.hpp:130 does).
+ *   Record = 16 floats, 64 bytes: v0.xyz, area | e1.xyz, bits(material index) |
+ *                                 e2.xyz, bits(prim id) | normal.xyz, bits(mesh index)
+ *   with e1, e2, normal, area precomputed as common/Triangle.hpp:52-59 does and
+ *   prim id = mesh base + triangle index within the mesh (Scene::Add order).
+ * tri_v12: v1.xyz, 0, v2.xyz, 0 per triangle (Triangle::Sample needs v1, v2
+ *   themselves, common/Triangle.hpp:75-82).
+ * node_area: BVHBuildNode::area per node (common/BVH.cpp:111,121,164), used by
+ *   the area-proportional descent of BVHAccel::getSample (common/BVH.hpp:147-177).
+ * All arrays must be 64-byte aligned. */
+typedef struct {
+    uint32_t num_nodes;
+    const float* nodes;     /* [num_nodes][8]  */
+    const float* node_area; /* [num_nodes]     */
+    uint32_t num_tris;
+    const float* tris;      /* [num_tris][16]  */
+    const float* tri_v12;   /* [num_tris][8]   */
+    uint32_t num_materials;
+    const hpt_material* materials;
+    uint32_t num_lights;
+    const hpt_light* lights;
+    float sum_light_area;   /* Scene::sumLightArea  (common/Scene.hpp:52) */
+    float sum_light_power;  /* Scene::sumLightPower (common/Scene.hpp:53) */
+    float cam_pos[3];       /* Scene::camPos */
+    float cam_scale;        /* tan(fov/2) as the host renderer computes it (common/Renderer.cpp:20) */
+    int32_t width, height;  /* Scene::width/height; aspect = width/(float)height */
+} hpt_scene_desc;
+
+typedef struct {
+    uint64_t closest_queries; /* closest-hit BVH queries  */
+    uint64_t shadow_queries;  /* any-hit (shadow) queries */
+    uint64_t paths;           /* camera paths started     */
+    double kernel_ms;         /* HIP-event time of the render kernels of the last hpt_render */
+    uint32_t launches;        /* kernel launches of the last hpt_render                      */
+    uint32_t _pad;
+} hpt_stats;
+
+const char* hpt_last_error(void);
+const char* hpt_version(void);
+
+/* cudaGetDeviceCount analogue (the reference always uses device 0). */
+int hpt_device_count(int* count);
+
+/* Replaces CudaRenderer::PrepareRender's allocations (gpu_path_tracer/CudaRenderer.cu:19-35)
+ * and CudaRenderer::FinishRender (:37-49). */
+int hpt_context_create(int device, hpt_ctx** out);
+int hpt_context_destroy(hpt_ctx* ctx);
+
+/* Replaces Scene::MallocCuda / Scene::FreeCuda (gpu_path_tracer/CudaPortable.cu:283-332).
+ * Uploading again replaces the previous scene. Also (re)allocates and clears
+ * the context's own accumulation buffer (3 x int64 per pixel). */
+int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* scene);
+
+/* Options that have no counterpart in the reference CLI.
+ *   seed: word 2 of the Philox counter (default 0)
+ *   wavefront_capacity: paths in flight per streamed batch (default 1<<22)   */
+int hpt_set_seed(hpt_ctx* ctx, uint32_t seed);
+int hpt_set_wavefront_capacity(hpt_ctx* ctx, uint64_t paths);
+
+/* thrust::fill(framebuffer, 0) of CudaRenderer::Render (gpu_path_tracer/CudaRenderer.cu:56).
+ * accum_dev = NULL clears the context's own buffer. */
+int hpt_accum_clear(hpt_ctx* ctx, int64_t* accum_dev, void* stream);
+
+/* Replaces the per-sample loop of CudaRenderer::Render / CudaRenderer::PathTrace
+ * (gpu_path_tracer/CudaRenderer.cu:58-61, :76-94) and the kernels behind it
+ * (SingleKernelRayTracing, GenerateCameraRay, ComputeIntersections,
+ * IntegratePathSegment, the two thrust compactions, FinalGather;
+ * gpu_path_tracer/CudaPathTrace.cu:14-160).
+ *
+ * Traces samples [sample_begin, sample_begin + sample_count) of every pixel
+ * and ADDS each path's radiance, in 40.24 fixed point, to accum_dev
+ * (int64[3*width*height], row-major pixels, RGB interleaved; NULL = the
+ * context's own buffer).  PathTrace(scene, iter) is sample_begin = iter,
+ * sample_count = 1.  The sample index is part of the RNG key, so any split of
+ * a sample range over calls, streams or GPUs yields the same sums.
+ *   mode:  HPT_MODE_SINGLE_KERNEL | HPT_MODE_STREAMED
+ *   block: workgroup size (the CLI's <threads>), 1..1024
+ * Asynchronous with respect to the host (work is queued on `stream`). */
+int hpt_render(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sample_begin, uint32_t sample_count,
+               int64_t* accum_dev, void* stream);
+
+/* Replaces the cudaMemcpy D2H of CudaRenderer::Render (gpu_path_tracer/CudaRenderer.cu:63-67):
+ * converts the accumulators to float RGB divided by spp_total (what
+ * Renderer::framebuffer holds in the reference) and copies them to host
+ * memory.  Synchronises `stream`. */
+int hpt_resolve(hpt_ctx* ctx, const int64_t* accum_dev, uint32_t spp_total, float* rgb_host, void* stream);
+/* same, result left in device memory (float[3*width*height]) */
+int hpt_resolve_dev(hpt_ctx* ctx, const int64_t* accum_dev, uint32_t spp_total, float* rgb_dev, void* stream);
+
+/* BVH queries on a fixed ray batch; the device counterpart of Scene::intersect
+ * (common/Scene.hpp:95-97 -> BVHAccel::Intersect, common/BVH.hpp:82-145).
+ *   o, d:   float[3*n] origins / directions
+ *   shadow: NULL or uint8[n]; non-zero = any-hit query with tmax[n] = Ray::shadowDistance
+ *   prim:   int32[n]  global primitive id, -1 = miss
+ *   t:      double[n] Intersection::distance (1e30f on a miss)
+ * Host-pointer form (copies in and out, synchronous) and device-pointer form
+ * (asynchronous on `stream`). */
+int hpt_intersect_batch(hpt_ctx* ctx, size_t n, const float* o, const float* d, const uint8_t* shadow,
+                        const double* tmax, int32_t* prim, double* t);
+int hpt_intersect_batch_dev(hpt_ctx* ctx, size_t n, const float* o_dev, const float* d_dev, const uint8_t* shadow_dev,
+                            const double* tmax_dev, int32_t* prim_dev, double* t_dev, int block, void* stream);
+
+/* Ray counters accumulated since the last hpt_stats_reset, timing of the last
+ * hpt_render.  Synchronises the device. */
+int hpt_stats_get(hpt_ctx* ctx, hpt_stats* out);
+int hpt_stats_reset(hpt_ctx* ctx);
+
+/* the context's own accumulation buffer (device pointer), for callers that
+ * reduce it across GPUs themselves */
+int hpt_accum_buffer(hpt_ctx* ctx, int64_t** accum_dev, size_t* num_elements);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HPT_H */

@@ -1,0 +1,58 @@
+/* hpt_host -- C view of the C++ host side (Scene / BVHAccel / HipRenderer in
+ * cudapathtracer_amd/host/), for callers that are not C++ (the Python package
+ * binds it with ctypes).  It adds no behaviour of its own: scenes are built by
+ * the same Scene::Add / Scene::buildBVH code the gpu_path_tracer CLI uses.
+ *
+ * Every function returns 0 on success; hpt_host_last_error() describes the
+ * last failure of the calling thread.
+ */
+#ifndef HPT_HOST_H
+#define HPT_HOST_H
+
+#include "hpt.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hpt_host_scene hpt_host_scene;
+
+const char* hpt_host_last_error(void);
+
+/* Scene::CreateBuiltinScene(CornellBox, max_depth) (common/Scene.cpp:25-73);
+ * models_dir = directory that contains cornellbox/ (NULL = "models" or
+ * $HPT_MODELS_DIR); width/height <= 0 keep the built-in 512x512. */
+int hpt_host_scene_cornell(const char* models_dir, int width, int height, int max_depth, hpt_host_scene** out);
+/* empty scene: Scene(w, h) + camera (common/Scene.hpp:23-45) */
+int hpt_host_scene_create(int width, int height, const float cam_pos[3], double fov_deg, int max_depth,
+                          hpt_host_scene** out);
+/* Scene::Add(new MeshTriangle(...)) (common/Scene.hpp:47-56, common/Triangle.cpp:5-61) */
+int hpt_host_scene_add_obj(hpt_host_scene* s, const char* obj_path, const hpt_material* material);
+int hpt_host_scene_add_triangles(hpt_host_scene* s, const float* verts9, int num_tris, const hpt_material* material);
+/* Scene::buildBVH (common/Scene.cpp:9-23) + flattening */
+int hpt_host_scene_build(hpt_host_scene* s);
+int hpt_host_scene_set_resolution(hpt_host_scene* s, int width, int height);
+int hpt_host_scene_destroy(hpt_host_scene* s);
+
+/* the flattened scene; pointers stay valid until the scene is destroyed or rebuilt */
+int hpt_host_scene_describe(const hpt_host_scene* s, hpt_scene_desc* out);
+/* leaf order -> global primitive id (num_tris entries) */
+int hpt_host_scene_prim_ids(const hpt_host_scene* s, int32_t* out);
+/* One level of the two-level BVH before flattening, pre-order: mesh = -1 for
+ * the top level (payload = mesh index), else the mesh's own BVH (payload =
+ * triangle index within the mesh); payload -1 = interior.  bounds6 = pMin,pMax.
+ * Returns the node count through *count; pass NULL arrays to only count. */
+int hpt_host_bvh_dump(const hpt_host_scene* s, int mesh, int* count, float* bounds6, int32_t* payload, float* area,
+                      int32_t* miss);
+
+/* HipRenderer: PrepareRender + Render + FinishRender on `device`; rgb =
+ * float[3*width*height] (Renderer::framebuffer).  stats may be NULL. */
+int hpt_host_render(const hpt_host_scene* s, int device, int spp, int max_depth, int num_threads, int mode, float* rgb,
+                    hpt_stats* stats);
+/* Utility::SavePPM (common/Utility.cpp:4-22) */
+int hpt_host_save_ppm(const char* path, const float* rgb, int width, int height);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HPT_HOST_H */

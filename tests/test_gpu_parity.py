@@ -1,0 +1,215 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU
+oracle on identical inputs.
+
+Bars: primitive ids, hit distances (float64 bits), any-hit results and the
+fixed-point radiance accumulators are compared BIT-EXACT -- the device
+arithmetic is specified operation by operation, so no tolerance is needed or
+used.  north_star's own bar for t is 1e-5 relative; it is asserted as well so
+that a failure of the stricter check still reports against the contract.
+"""
+import numpy as np
+import pytest
+
+from orclib import (RNG_PHILOX, TRIG_PORTABLE, primary_rays, random_rays, shadow_rays)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cornell(hp, oracle, gpu_ctx):
+    sc = hp.Scene.CreateBuiltinScene(hp.Scene.CornellBox, 5)
+    osc = oracle.cornell()
+    gpu_ctx.upload(sc)
+    return sc, osc, gpu_ctx
+
+
+def _check_hits(got, want, what):
+    gp, gt = got
+    wp, wt = want
+    bad = np.flatnonzero(gp != wp)
+    assert bad.size == 0, "%s: %d primitive ids differ, first ray %d: gpu %d oracle %d" % (
+        what, bad.size, bad[0], gp[bad[0]], wp[bad[0]])
+    rel = np.abs(gt - wt) / np.maximum(np.abs(wt), 1e-30)
+    assert rel.max() <= 1e-5, "%s: t differs by %g relative" % (what, rel.max())
+    bad = np.flatnonzero(gt.view(np.int64) != wt.view(np.int64))
+    assert bad.size == 0, "%s: %d hit distances differ in bits (max rel %g)" % (what, bad.size, rel.max())
+
+
+def test_intersect_primary_grid(cornell):
+    sc, osc, ctx = cornell
+    o, d = primary_rays(512, 512, (278, 273, -800), osc.info()["cam_scale"])
+    want = osc.intersect(o, d)
+    assert (want[0] >= 0).sum() == 234737  # known answer of the compiled reference
+    _check_hits(ctx.intersect(o, d), want, "primary grid")
+
+
+def test_intersect_random_closest(cornell):
+    sc, osc, ctx = cornell
+    o, d = random_rays(1 << 18, seed=1)
+    _check_hits(ctx.intersect(o, d), osc.intersect(o, d), "random closest")
+
+
+def test_intersect_shadow(cornell):
+    sc, osc, ctx = cornell
+    o, d, sh, tm = shadow_rays(1 << 18, seed=2)
+    want = osc.intersect(o, d, sh, tm)
+    assert 0 < (want[0] >= 0).mean() < 1
+    _check_hits(ctx.intersect(o, d, sh, tm), want, "shadow")
+
+
+def test_intersect_mixed_and_degenerate(cornell):
+    """closest and any-hit queries interleaved in one batch; axis-parallel
+    directions (infinite reciprocal, NaN slab products); rays starting on surfaces."""
+    sc, osc, ctx = cornell
+    o1, d1 = random_rays(4096, seed=3)
+    o2, d2, _, tm2 = shadow_rays(4096, seed=4)
+    o = np.concatenate([o1, o2])
+    d = np.concatenate([d1, d2])
+    sh = np.concatenate([np.zeros(4096, np.uint8), np.ones(4096, np.uint8)])
+    tm = np.concatenate([np.zeros(4096), tm2])
+    perm = np.random.RandomState(5).permutation(len(o))
+    o, d, sh, tm = o[perm], d[perm], sh[perm], tm[perm]
+    _check_hits(ctx.intersect(o, d, sh, tm), osc.intersect(o, d, sh, tm), "mixed")
+    axes = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1], [0, -0.0, 1], [1, 1, 0]], np.float32)
+    axes[-1] /= np.float32(np.sqrt(2))
+    rs = np.random.RandomState(6)
+    o = (rs.rand(8 * 512, 3) * [556, 548.8, 559.2]).astype(np.float32)
+    o[::7, 1] = 0.0      # on the floor plane
+    o[::11, 0] = 0.0     # on the right wall plane
+    d = np.tile(axes, (512, 1))
+    _check_hits(ctx.intersect(o, d), osc.intersect(o, d), "axis-parallel")
+
+
+def test_intersect_empty_batch(cornell):
+    sc, osc, ctx = cornell
+    p, t = ctx.intersect(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
+    assert p.shape == (0,) and t.shape == (0,)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("depth,spp", [(5, 4), (20, 3)])
+def test_render_matches_oracle_bit_exact(hp, oracle, gpu_ctx, mode, depth, spp):
+    w = h = 96
+    sc = hp.Scene.CreateBuiltinScene(hp.Scene.CornellBox, depth, w, h)
+    osc = oracle.cornell(w, h)
+    gpu_ctx.upload(sc)
+    gpu_ctx.stats_reset()
+    gpu_ctx.accum_clear()
+    gpu_ctx.render(mode, 256, depth, 0, spp)
+    got = gpu_ctx.resolve(spp)
+    st = gpu_ctx.stats()
+    want_acc, ost = osc.render(RNG_PHILOX, TRIG_PORTABLE, depth, spp, fixed=True)
+    want = oracle.resolve(want_acc, spp)
+    assert st["paths"] == ost["paths"] == w * h * spp
+    assert st["closest_queries"] == ost["closest_queries"]
+    assert st["shadow_queries"] == ost["shadow_queries"]
+    bad = np.flatnonzero((got.view(np.int32) != want.view(np.int32)).any(axis=1))
+    assert bad.size == 0, "%d of %d pixels differ, max abs diff %g" % (bad.size, w * h, np.abs(got - want).max())
+
+
+def test_accumulators_bit_exact_and_split_invariant(hp, oracle, gpu_ctx):
+    """raw int64 accumulators == oracle's; [0,6) == [0,2) + [2,6); mode 1 == mode 2."""
+    import ctypes as C
+    w, h, depth, spp = 64, 48, 8, 6
+    sc = hp.Scene.CreateBuiltinScene(hp.Scene.CornellBox, depth, w, h)
+    gpu_ctx.upload(sc)
+    osc = oracle.cornell(w, h)
+    want, _ = osc.render(RNG_PHILOX, TRIG_PORTABLE, depth, spp, fixed=True)
+
+    def download():
+        ptr, n = gpu_ctx.accum_buffer()
+        out = np.zeros(n, np.int64)
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        assert hip.hipDeviceSynchronize() == 0
+        assert hip.hipMemcpy(out.ctypes.data, ptr, n * 8, 2) == 0
+        return out.reshape(-1, 3)
+
+    gpu_ctx.accum_clear()
+    gpu_ctx.render(1, 256, depth, 0, spp)
+    a = download()
+    assert np.array_equal(a, want)
+    gpu_ctx.accum_clear()
+    gpu_ctx.render(1, 128, depth, 0, 2)
+    gpu_ctx.render(2, 64, depth, 2, 4)
+    assert np.array_equal(download(), want)
+
+
+@pytest.mark.parametrize("block", [64, 100, 512, 1024])
+@pytest.mark.parametrize("mode", [1, 2])
+def test_block_sizes_give_identical_images(hp, oracle, gpu_ctx, block, mode):
+    w, h, depth, spp = 40, 24, 6, 2   # 40x24: partial 8x8 tiles on neither edge... 24 = 3 tiles, 40 = 5 tiles
+    sc = hp.Scene.CreateBuiltinScene(hp.Scene.CornellBox, depth, w + 3, h + 5)  # ragged edges
+    osc = oracle.cornell(w + 3, h + 5)
+    gpu_ctx.upload(sc)
+    gpu_ctx.accum_clear()
+    gpu_ctx.render(mode, block, depth, 0, spp)
+    got = gpu_ctx.resolve(spp)
+    want_acc, _ = osc.render(RNG_PHILOX, TRIG_PORTABLE, depth, spp, fixed=True)
+    assert np.array_equal(got.view(np.int32), oracle.resolve(want_acc, spp).view(np.int32))
+
+
+def test_cpp_hiprenderer_equals_c_abi(hp, oracle, gpu_ctx):
+    """the C++ HipRenderer class (PrepareRender/Render/FinishRender) and the Python mirror."""
+    w = h = 64
+    sc = hp.Scene.CreateBuiltinScene(hp.Scene.CornellBox, 5, w, h)
+    osc = oracle.cornell(w, h)
+    want_acc, _ = osc.render(RNG_PHILOX, TRIG_PORTABLE, 5, 4, fixed=True)
+    want = oracle.resolve(want_acc, 4)
+    for mode in (1, 2):
+        rgb, st = sc.render_cpp(4, 5, 256, mode)
+        assert st["paths"] == w * h * 4
+        assert np.array_equal(rgb.view(np.int32), want.view(np.int32))
+    r = hp.HipRenderer()
+    r.spp = 4
+    r.SetMode(hp.Streamed)
+    r.PrepareRender(sc)
+    fb = r.Render(sc)
+    assert np.array_equal(fb.view(np.int32), want.view(np.int32))
+    # PathTrace(scene, iter): one sample per call on top of a cleared buffer
+    r.PrepareRender(sc)
+    for it in range(4):
+        r.PathTrace(sc, it)
+    assert np.array_equal(r.framebuffer.view(np.int32), want.view(np.int32))
+    r.FinishRender(sc)
+
+
+def test_wavefront_small_capacity_batches(hp, oracle, gpu_ctx):
+    """streamed mode with a queue far smaller than the number of paths"""
+    w, h, depth, spp = 72, 40, 7, 5
+    sc = hp.Scene.CreateBuiltinScene(hp.Scene.CornellBox, depth, w, h)
+    gpu_ctx.upload(sc)
+    gpu_ctx.set_wavefront_capacity(4096)
+    try:
+        gpu_ctx.accum_clear()
+        gpu_ctx.render(2, 256, depth, 0, spp)
+        got = gpu_ctx.resolve(spp)
+    finally:
+        gpu_ctx.set_wavefront_capacity(1 << 22)
+    want_acc, _ = oracle.cornell(w, h).render(RNG_PHILOX, TRIG_PORTABLE, depth, spp, fixed=True)
+    assert np.array_equal(got.view(np.int32), oracle.resolve(want_acc, spp).view(np.int32))
+
+
+def test_error_paths(hp, gpu_ctx):
+    sc = hp.Scene.CreateBuiltinScene(hp.Scene.CornellBox, 5, 16, 16)
+    gpu_ctx.upload(sc)
+    with pytest.raises(hp.HptError):
+        gpu_ctx.render(3, 256, 5, 0, 1)          # bad mode
+    with pytest.raises(hp.HptError):
+        gpu_ctx.render(1, 0, 5, 0, 1)            # bad block
+    with pytest.raises(hp.HptError):
+        gpu_ctx.render(1, 2048, 5, 0, 1)
+    fresh = hp.Context(0)
+    with pytest.raises(hp.HptError):
+        fresh.render(1, 256, 5, 0, 1)            # no scene
+    fresh.close()
+    d = sc.describe()
+    d.num_nodes = 0
+    with pytest.raises(hp.HptError):
+        gpu_ctx.upload(d)
+    # zero samples / zero depth are no-ops, not errors (castRay's loop does not run)
+    gpu_ctx.upload(sc)
+    gpu_ctx.accum_clear()
+    gpu_ctx.render(1, 256, 0, 0, 4)
+    gpu_ctx.render(2, 256, 5, 0, 0)
+    assert not gpu_ctx.resolve(1).any()
