@@ -40,7 +40,7 @@ HD float dot(f3 a, f3 b) {
 HD f3 cross(f3 x, f3 y) { return mk(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y); }
 HD float length(f3 v) { return sqrtf(dot(v, v)); }
 HD f3 normalize(f3 v) { return v * (1.0f / sqrtf(dot(v, v))); }
-HD float gmax(float x, float y) { return (x < y) ? y : x; }  // glm::max
+HD float gmax(float x, float y) { return x > y ? x : y; }  // glm::max (external/glm/detail/func_common.inl:23-28): NaN -> y
 HD f3 xyz(float4 v) { return mk(v.x, v.y, v.z); }
 
 // common/MathUtils.hpp:64-74

@@ -9,6 +9,7 @@
 
 namespace {
 unsigned char tone(float v) {
+    if (!(v == v)) return 0;  // NaN: the reference's conversion of a NaN product yields 0 on x86-64
     const float c = vmax(0.f, vmin(1.f, v));
     return (unsigned char)(255 * std::pow(c, 0.6f));
 }

@@ -23,7 +23,8 @@ inline float dot(Vec3 a, Vec3 b) {
 inline Vec3 cross(Vec3 x, Vec3 y) { return Vec3(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y); }
 inline float length(Vec3 v) { return std::sqrt(dot(v, v)); }
 inline Vec3 normalize(Vec3 v) { return v * (1.0f / std::sqrt(dot(v, v))); }
-inline float vmin(float x, float y) { return (y < x) ? y : x; }
-inline float vmax(float x, float y) { return (x < y) ? y : x; }
+// scalar min/max of the reference's vector library (external/glm/detail/func_common.inl:15-28)
+inline float vmin(float x, float y) { return x < y ? x : y; }
+inline float vmax(float x, float y) { return x > y ? x : y; }
 inline Vec3 vmin(Vec3 a, Vec3 b) { return Vec3(vmin(a.x, b.x), vmin(a.y, b.y), vmin(a.z, b.z)); }
 inline Vec3 vmax(Vec3 a, Vec3 b) { return Vec3(vmax(a.x, b.x), vmax(a.y, b.y), vmax(a.z, b.z)); }

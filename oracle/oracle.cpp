@@ -49,8 +49,8 @@ static inline V3 cross(V3 x, V3 y) {
 }
 static inline float length(V3 v) { return std::sqrt(dot(v, v)); }
 static inline V3 normalize(V3 v) { return v * (1.0f / std::sqrt(dot(v, v))); }
-static inline float gmin(float x, float y) { return (y < x) ? y : x; }  // glm::min
-static inline float gmax(float x, float y) { return (x < y) ? y : x; }  // glm::max
+static inline float gmin(float x, float y) { return x < y ? x : y; }  // glm::min (detail/func_common.inl:15-19)
+static inline float gmax(float x, float y) { return x > y ? x : y; }  // glm::max (detail/func_common.inl:23-28)
 static inline V3 gmin(V3 a, V3 b) { return mk(gmin(a.x, b.x), gmin(a.y, b.y), gmin(a.z, b.z)); }
 static inline V3 gmax(V3 a, V3 b) { return mk(gmax(a.x, b.x), gmax(a.y, b.y), gmax(a.z, b.z)); }
 

@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures in this directory from the COMPILED REFERENCE
+(oracle/_ref/libref.so, built by `make ref` from the unmodified sources under
+/root/reference).  Runs only in the build container; the fixtures are data
+(inputs are regenerated from seeds by tests/orclib.py, only expected outputs
+and small input tables are stored).
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from orclib import Material, Ref, fnv1a64, primary_rays, random_rays, shadow_rays  # noqa: E402
+
+CAM = (278, 273, -800)
+
+
+def main():
+    R = Ref().cornell(5)
+    info = R.info()
+    assert info["num_tris"] == 32 and info["node_counter"] == 69
+
+    # ---- BVH: both levels, pre-order ---------------------------------
+    bvh = {}
+    for mesh in range(-1, info["num_meshes"]):
+        d = R.bvh_dump(mesh)
+        for k, v in d.items():
+            bvh["m%d_%s" % (mesh, k)] = v
+    for mesh in range(info["num_meshes"]):
+        mi = R.mesh_info(mesh)
+        bvh["mesh%d_info" % mesh] = np.array([mi["num_tris"], mi["area"], mi["bvh_root_area"]], np.float64)
+        bvh["mesh%d_bbox" % mesh] = mi["bbox"]
+        bvh["mesh%d_tris" % mesh] = R.mesh_triangles(mesh)
+    bvh["light_totals"] = np.array([info["sum_light_area"], info["sum_light_power"]], np.float32)
+    np.savez_compressed(os.path.join(HERE, "cornell_bvh.npz"), **bvh)
+
+    # ---- hit records on fixed ray batches ----------------------------
+    # camera scale exactly as the reference renderer computes it: recover it from
+    # the oracle-independent route (float32 maths of Renderer.cpp:11,20)
+    half_deg = np.float32(40 * 0.5)
+    half_rad = np.float32(np.float64(half_deg * np.float32(3.1415926535897932384626)) / 180.0)
+    scale = np.float32(np.tan(np.float64(half_rad)))
+    hits = {"cam_scale": np.array([scale], np.float32)}
+    o, d = primary_rays(512, 512, CAM, scale)
+    p, t, agree, cnt = R.intersect(o, d)
+    assert agree.all()
+    hits["grid512_hits"] = np.array([(p >= 0).sum()], np.int64)
+    hits["grid512_fnv"] = np.array([fnv1a64(p, t)], np.uint64)
+    hits["grid512_counts_mean"] = cnt.mean(0)
+    o, d = primary_rays(128, 128, CAM, scale)
+    p, t, agree, _ = R.intersect(o, d)
+    assert agree.all()
+    hits["grid128_prim"], hits["grid128_t"] = p, t
+    o, d = random_rays(8192, 1)
+    p, t, agree, _ = R.intersect(o, d)
+    assert agree.all()
+    hits["rand_prim"], hits["rand_t"] = p, t
+    o, d, sh, tm = shadow_rays(8192, 2)
+    p, t, agree, _ = R.intersect(o, d, sh, tm)
+    assert agree.all()
+    hits["shadow_prim"], hits["shadow_t"] = p, t
+    np.savez_compressed(os.path.join(HERE, "cornell_hits.npz"), **hits)
+
+    # ---- images rendered by the reference renderer -------------------
+    img = {}
+    R.cornell(5)
+    R.set_resolution(64, 64)
+    img["r64_d5_spp4"] = R.render(4)
+    R.cornell(20)
+    R.set_resolution(48, 40)
+    img["r48x40_d20_spp3"] = R.render(3)
+    # Renderer::Render == per-path castRay loop (harness self-check)
+    k = np.repeat(np.arange(3), 48 * 40)
+    m = np.tile(np.arange(48 * 40), 3)
+    L = R.cast_paths(k, m).reshape(3, -1, 3)
+    acc = np.zeros((48 * 40, 3), np.float32)
+    for s in range(3):
+        acc += L[s] / np.float32(3)
+    assert np.array_equal(acc, img["r48x40_d20_spp3"])
+    # converged-ish image + noise floor: two independent 64-spp renders at 96x96, depth 20
+    R.set_resolution(96, 96)
+    P = 96 * 96
+    a = np.zeros((P, 3), np.float64)
+    b = np.zeros((P, 3), np.float64)
+    for s in range(64):
+        a += R.cast_paths(np.full(P, s), np.arange(P))
+        b += R.cast_paths(np.full(P, 64 + s), np.arange(P))
+    a, b = (a / 64).astype(np.float32), (b / 64).astype(np.float32)
+    img["r96_d20_spp64_a"] = a
+    img["r96_d20_spp64_b_mean"] = b.mean(0)
+    ca, cb = np.clip(a, 0, 1), np.clip(b, 0, 1)
+    img["r96_d20_noise_rmse_clamped"] = np.array([np.sqrt(((ca - cb) ** 2).mean())], np.float64)
+    img["r96_d20_noise_rmse"] = np.array([np.sqrt(((a - b) ** 2).mean())], np.float64)
+    np.savez_compressed(os.path.join(HERE, "cornell_images.npz"), **img)
+
+    # ---- shading vectors ---------------------------------------------
+    sh = {}
+    rs = np.random.RandomState(7)
+    n = 2048
+
+    def unit(v):
+        return (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+
+    nrm = unit(rs.randn(n, 3))
+    nrm[:6] = np.array([[0, 1, 0], [0, -1, 0], [1, 0, 0], [-1, 0, 0], [0, 0, 1], [0, 0, -1]], np.float32)
+    wo = unit(rs.randn(n, 3))
+    wi = unit(rs.randn(n, 3))
+    flip = (wo * nrm).sum(1) < 0
+    flip[3 * n // 4:] = False     # observer on the front side for 3/4 of the vectors, anywhere for the rest
+    wo[flip] = -wo[flip]
+    sh["nrm"], sh["wo"], sh["wi"] = nrm, wo, wi
+    mats = {
+        "lambert": Material.make(0, albedo=(0.725, 0.71, 0.68)),
+        "metal": Material.make(1, albedo=(0.7, 0.5, 0.2), metallic=1.0, roughness=0.005),
+        "metal_rough": Material.make(1, albedo=(0.9, 0.6, 0.3), metallic=0.3, roughness=0.4),
+    }
+    for name, m in mats.items():
+        bs, pdf = R.material_eval(m, wi, wo, nrm)
+        sh[name + "_bsdf"], sh[name + "_pdf"] = bs, pdf
+        w, u = R.material_sample(m, 100, 17, wo, nrm)
+        sh[name + "_sample_wi"], sh[name + "_sample_u"] = w, u
+        # evaluated at the sampled direction too (the integrator's use)
+        bs, pdf = R.material_eval(m, w, wo, nrm)
+        sh[name + "_bsdf_at_sample"], sh[name + "_pdf_at_sample"] = bs, pdf
+    rx, ry = rs.rand(n).astype(np.float32), rs.rand(n).astype(np.float32)
+    sh["hemi_rx"], sh["hemi_ry"] = rx, ry
+    sh["hemi_out"] = R.sample_hemisphere_cosine(nrm, rx, ry)
+    R.cornell(5)
+    out, u = R.sample_light(1024, 500, 3)
+    sh["light_out"], sh["light_u"] = out, u
+    sh["rng_k3_m12345"] = R.rng_floats(3, 12345, 64)
+    sh["rng_k0_m0"] = R.rng_floats(0, 0, 64)
+    f = rs.rand(256).astype(np.float32) * 3
+    g = rs.rand(256).astype(np.float32) * 3
+    f[0], g[1] = np.inf, np.inf
+    sh["mis_f"], sh["mis_g"] = f, g
+    sh["mis_w"] = np.array([R.lib.ref_power_heuristic(float(a), float(b)) for a, b in zip(f, g)], np.float32)
+    tv = np.concatenate([np.linspace(-0.5, 1.5, 401), [np.nan]]).astype(np.float32)
+    sh["tone_in"] = tv
+    sh["tone_out"] = np.array([R.lib.ref_tonemap(float(v)) for v in tv], np.int32)
+    np.savez_compressed(os.path.join(HERE, "cornell_shading.npz"), **sh)
+    for f in sorted(os.listdir(HERE)):
+        print("%8d  %s" % (os.path.getsize(os.path.join(HERE, f)), f))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,226 @@
+"""CPU-side tests of the product's host code: BVH topology and flattened layout
+against the reference fixtures and the oracle, C-ABI libraries load and export
+every declared symbol, PPM writer, error behaviour.  No GPU compute is called."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from orclib import primary_rays, random_rays, shadow_rays
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.int32) if a.dtype == np.float32 else a
+
+
+@pytest.fixture(scope="module")
+def cornell(hp):
+    return hp.Scene.CreateBuiltinScene(hp.Scene.CornellBox, 5)
+
+
+def test_libraries_export_every_declared_symbol(hp):
+    hpt, host = hp.load_libraries()
+    for header, lib in (("hpt.h", hpt), ("hpt_host.h", host)):
+        text = open(os.path.join(ROOT, "include", header)).read()
+        names = set(re.findall(r"\b(hpt_[a-z_0-9]+)\s*\(", text))
+        assert len(names) >= 10
+        for n in sorted(names):
+            assert hasattr(lib, n), "%s declares %s but the library does not export it" % (header, n)
+    assert b"gfx950" in hpt.hpt_version()
+    # the library is built for gfx950 only
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--list", "--type=o",
+                          "--input=" + os.path.join(ROOT, "cudapathtracer_amd", "libhpt.so")],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True).stdout if os.path.exists(
+        "/opt/rocm/lib/llvm/bin/clang-offload-bundler") else "gfx950"
+    assert "gfx950" in out or out.strip() == ""
+
+
+def test_host_bvh_equals_reference_fixture(cornell):
+    g = np.load(os.path.join(G, "cornell_bvh.npz"))
+    for mesh in range(-1, 6):
+        d = cornell.bvh_dump(mesh)
+        for k in ("bounds", "payload", "area", "miss"):
+            assert np.array_equal(bits(d[k]), bits(g["m%d_%s" % (mesh, k)])), (mesh, k)
+
+
+def test_flattened_layout(cornell):
+    g = np.load(os.path.join(G, "cornell_bvh.npz"))
+    f = cornell.flat_arrays()
+    nodes, tris = f["nodes"], f["tris"]
+    # 11 top-level nodes, 6 of them leaves replaced by mesh BVHs of 11+19+19+3+3+3 nodes
+    assert nodes.shape == (5 + 58, 8) and tris.shape == (32, 16)
+    miss, leaf = nodes.view(np.int32)[:, 3], nodes.view(np.int32)[:, 7]
+    assert sorted(leaf[leaf >= 0]) == list(range(32)), "every triangle is referenced by exactly one leaf"
+    assert (leaf[leaf >= 0] == np.arange(32)).all(), "triangles are stored in the order the traversal meets them"
+    assert (miss > np.arange(len(nodes))).all() and miss.max() == len(nodes)
+    # leaf order of prim ids: top level meets meshes 4 1 0 2 3 5, each in its own leaf order
+    base = [0, 6, 16, 26, 28, 30]
+    want = []
+    for m in [4, 1, 0, 2, 3, 5]:
+        want += [base[m] + int(x) for x in g["m%d_payload" % m] if x >= 0]
+    assert list(f["prim_of_tri"]) == want
+    assert list(tris.view(np.int32)[:, 11]) == want
+    # triangle records carry the reference's precomputed v0/e1/e2/normal/area
+    for t in range(32):
+        prim = want[t]
+        m = max(i for i in range(6) if base[i] <= prim)
+        ref = g["mesh%d_tris" % m][prim - base[m]]
+        assert np.array_equal(bits(tris[t, [0, 1, 2, 4, 5, 6, 8, 9, 10, 12, 13, 14]]), bits(ref[:12]))
+        assert bits(tris[t, 3:4])[0] == bits(ref[12:13])[0]
+        assert tris.view(np.int32)[t, 7] == m and tris.view(np.int32)[t, 15] == m
+    assert f["lights"] == [(13650.0, 13650.0, 60, 5)]
+    assert np.array_equal(bits(np.array([f["sum_light_area"], f["sum_light_power"]], np.float32)), bits(g["light_totals"]))
+    d = cornell.describe()
+    for p in (d.nodes, d.tris, d.tri_v12, d.node_area):
+        assert C.cast(p, C.c_void_p).value % 64 == 0, "flattened arrays are 64-byte aligned"
+
+
+def _walk(f, o, d, shadow=False, tmax=0.0):
+    """Plain-Python walk of the flattened arrays with the same rules the device
+    kernel uses; float32 arithmetic via numpy scalars."""
+    F = np.float32
+    nodes, tris = f["nodes"], f["tris"]
+    ni, ti = nodes.view(np.int32), tris.view(np.int32)
+    with np.errstate(all="ignore"):
+        inv = (F(1) / d).astype(np.float32)
+        neg = d < 0
+        best, best_t = -1, float(F(1e30))
+        limit = tmax - float(F(5) * F(1e-4))
+        node, end = 0, len(nodes)
+        while node < end:
+            lo, hi = nodes[node, 0:3], nodes[node, 4:7]
+            a, b = ((lo - o) * inv).astype(np.float32), ((hi - o) * inv).astype(np.float32)
+            tmin3, tmax3 = np.where(neg, b, a), np.where(neg, a, b)
+            tMin, tMax = tmin3[0], tmax3[0]
+            hit = not ((tMin > tmax3[1]) or (tmin3[1] > tMax))
+            if tmin3[1] > tMin:
+                tMin = tmin3[1]
+            if tmax3[1] < tMax:
+                tMax = tmax3[1]
+            hit = hit and not ((tMin > tmax3[2]) or (tmin3[2] > tMax))
+            if not hit:
+                node = ni[node, 3]
+                continue
+            tri = ni[node, 7]
+            node += 1
+            if tri < 0:
+                continue
+            T = tris[tri]
+            v0, e1, e2, n = T[0:3], T[4:7], T[8:11], T[12:15]
+            dot = lambda p, q: F(F(F(p[0] * q[0]) + F(p[1] * q[1])) + F(p[2] * q[2]))
+            cross = lambda x, y: np.array([F(x[1] * y[2]) - F(y[1] * x[2]), F(x[2] * y[0]) - F(y[2] * x[0]),
+                                           F(x[0] * y[1]) - F(y[0] * x[1])], np.float32)
+            if dot(d, n) > 0:
+                continue
+            pvec = cross(d, e2)
+            det = float(dot(e1, pvec))
+            if abs(det) < float(F(1e-5)):
+                continue
+            det_inv = 1.0 / det
+            tvec = (o - v0).astype(np.float32)
+            u = float(dot(tvec, pvec)) * det_inv
+            if u < 0 or u > 1:
+                continue
+            qvec = cross(tvec, e1)
+            v = float(dot(d, qvec)) * det_inv
+            if v < 0 or u + v > 1:
+                continue
+            t = float(dot(e2, qvec)) * det_inv
+            if t < 0:
+                continue
+            if shadow:
+                if t < limit:
+                    return int(ti[tri, 11]), t
+            elif t < best_t:
+                best, best_t = int(ti[tri, 11]), t
+    return best, best_t
+
+
+def test_flattened_tree_walk_equals_oracle(cornell, oracle):
+    """The single flattened tree gives the two-level reference traversal's answers."""
+    f = cornell.flat_arrays()
+    osc = oracle.cornell()
+    o1, d1 = primary_rays(16, 16, (278, 273, -800), f["cam_scale"])
+    o2, d2 = random_rays(200, 21)
+    o = np.concatenate([o1, o2])
+    d = np.concatenate([d1, d2])
+    wp, wt = osc.intersect(o, d)
+    for r in range(len(o)):
+        p, t = _walk(f, o[r], d[r])
+        assert p == wp[r] and t == wt[r], (r, p, wp[r], t, wt[r])
+    o, d, sh, tm = shadow_rays(150, 22)
+    wp, wt = osc.intersect(o, d, sh, tm)
+    for r in range(len(o)):
+        p, t = _walk(f, o[r], d[r], True, tm[r])
+        assert (p >= 0) == (wp[r] >= 0), r
+        if p >= 0:
+            assert t < tm[r]
+
+
+def test_custom_scene_and_bunny_topology(hp, oracle):
+    """4968-triangle mesh: std::sort over more than 16 equal-ish keys; leaf order must
+    equal the oracle's (which equals the compiled reference's where that is present)."""
+    bunny = os.path.join(ROOT, "models", "bunny", "bunny.obj")
+    sc = hp.Scene(32, 24, camPos=(0, 0.1, -0.4), fov=40, maxDepth=4)
+    sc.Add(bunny, hp.Material(0, albedo=(0.7, 0.7, 0.7)))
+    quad = np.array([[[-.05, .25, -.05], [.05, .25, .05], [-.05, .25, .05]],
+                     [[-.05, .25, -.05], [.05, .25, -.05], [.05, .25, .05]]], np.float32)
+    sc.Add(quad, hp.Material(0, emission=(20, 20, 20)))
+    sc.buildBVH()
+    from orclib import Material
+    osc = oracle.scene(32, 24, (0, 0.1, -0.4), 40)
+    osc.add_obj(bunny, Material.make(0, albedo=(0.7, 0.7, 0.7)))
+    osc.add_triangles(quad, Material.make(0, emission=(20, 20, 20)))
+    osc.build()
+    for mesh in (-1, 0, 1):
+        a, b = sc.bvh_dump(mesh), osc.bvh_dump(mesh)
+        for k in a:
+            assert np.array_equal(bits(a[k]), bits(b[k])), (mesh, k)
+    f = sc.flat_arrays()
+    assert f["nodes"].shape[0] == 1 + (2 * 4968 - 1) + 3 and f["tris"].shape[0] == 4970
+    assert len(f["lights"]) == 1 and f["lights"][0][3] == 1
+
+
+def test_scene_errors(hp, tmp_path):
+    with pytest.raises(hp.HptError):
+        hp.Scene.CreateBuiltinScene(hp.Scene.CornellBox, 5, models_dir=str(tmp_path))
+    sc = hp.Scene(8, 8)
+    with pytest.raises(hp.HptError):
+        sc.Add(str(tmp_path / "missing.obj"), hp.Material())
+    quadface = tmp_path / "quad.obj"
+    quadface.write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nf 1 2 3 4\n")
+    with pytest.raises(hp.HptError):
+        sc.Add(str(quadface), hp.Material())
+    with pytest.raises(hp.HptError):
+        sc.buildBVH()          # no meshes
+    with pytest.raises(hp.HptError):
+        sc.describe()          # not built
+    with pytest.raises(hp.HptError):
+        hp.Scene.CreateBuiltinScene(1, 5)
+
+
+def test_save_ppm_tone_curve(hp, tmp_path):
+    g = np.load(os.path.join(G, "cornell_shading.npz"))
+    v = g["tone_in"]
+    n = len(v)
+    fb = np.stack([v, v, v], -1).astype(np.float32)
+    path = tmp_path / "t.ppm"
+    hp.SavePPM(str(path), fb, n, 1)
+    raw = path.read_bytes()
+    header = b"P6\n%d 1\n255\n" % n
+    assert raw.startswith(header) and len(raw) == len(header) + 3 * n
+    px = np.frombuffer(raw[len(header):], np.uint8).reshape(n, 3)
+    assert np.array_equal(px[:, 0].astype(np.int32), g["tone_out"]) and (px[:, 0] == px[:, 2]).all()
+    with pytest.raises(hp.HptError):
+        hp.SavePPM(str(tmp_path / "no_such_dir" / "x.ppm"), fb, n, 1)
+
+
+def test_cli_is_built():
+    assert os.access(os.path.join(ROOT, "build", "gpu_path_tracer"), os.X_OK)
