@@ -77,7 +77,8 @@ def load_libraries():
     global _libs
     if _libs is not None:
         return _libs
-    paths = [os.path.join(_PKG, "libhpt.so"), os.path.join(_PKG, "libhpt_host.so")]
+    # HPT_LIBHPT: load a differently built kernel library (A/B experiments)
+    paths = [os.environ.get("HPT_LIBHPT") or os.path.join(_PKG, "libhpt.so"), os.path.join(_PKG, "libhpt_host.so")]
     for p in paths:
         if not os.path.exists(p):
             raise HptError("%s is missing: build it with `make hpt host` (or __graft_entry__.build()); "

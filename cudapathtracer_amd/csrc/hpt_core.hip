@@ -66,20 +66,20 @@ __device__ __forceinline__ bool lane_to_pixel(const DevScene& S, uint32_t g, uin
     return x < (uint32_t)S.width && y < (uint32_t)S.height;
 }
 
-template <bool kLds>
+template <int kScene>
 __global__ void k_intersect_batch(DevScene S, size_t n, const float* __restrict__ o, const float* __restrict__ d,
                                   const uint8_t* __restrict__ shadow, const double* __restrict__ tmax,
                                   int32_t* __restrict__ prim, double* __restrict__ t_out) {
     extern __shared__ float4 lds[];
-    if constexpr (kLds) stage_scene_lds(S, lds);
+    if constexpr (kScene != kSceneGlobal) stage_scene_lds(S, lds);
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) {
         const f3 ro = mk(o[3 * r], o[3 * r + 1], o[3 * r + 2]);
         const f3 rd = mk(d[3 * r], d[3 * r + 1], d[3 * r + 2]);
         int tri;
         double t;
-        if (shadow && shadow[r]) trace<kLds, true>(S, lds, ro, rd, tmax[r], tri, t);
-        else trace<kLds, false>(S, lds, ro, rd, 0.0, tri, t);
+        if (shadow && shadow[r]) trace<kScene, true>(S, lds, ro, rd, tmax[r], tri, t);
+        else trace<kScene, false>(S, lds, ro, rd, 0.0, tri, t);
         prim[r] = tri < 0 ? -1 : __float_as_int(S.tris[4 * tri + 2].w);
         t_out[r] = t;
     }
@@ -92,12 +92,15 @@ __device__ __forceinline__ void accumulate_pixel(int64_t* accum, uint32_t pixel,
     atomicAdd(a + 2, (unsigned long long)radiance_to_fixed(rad.z));
 }
 
-template <bool kLds, int kMaxBlock>
-__global__ void __launch_bounds__(kMaxBlock)
+#ifndef HPT_MEGA_WAVES
+#define HPT_MEGA_WAVES 1
+#endif
+template <int kScene, int kMaxBlock>
+__global__ void __launch_bounds__(kMaxBlock, (kMaxBlock == 256 ? HPT_MEGA_WAVES : 1))
 k_render_mega(DevScene S, int max_depth, uint32_t s_begin, uint32_t s_end, int64_t* __restrict__ accum,
               unsigned long long* __restrict__ stats) {
     extern __shared__ float4 lds[];
-    if constexpr (kLds) stage_scene_lds(S, lds);
+    if constexpr (kScene != kSceneGlobal) stage_scene_lds(S, lds);
     uint32_t pixel;
     const bool valid = lane_to_pixel(S, blockIdx.x * blockDim.x + threadIdx.x, pixel);
     uint32_t n_closest = 0, n_shadow = 0, n_paths = 0;
@@ -116,8 +119,8 @@ k_render_mega(DevScene S, int max_depth, uint32_t s_begin, uint32_t s_end, int64
             int tri;
             double t;
             ++n_closest;
-            trace<kLds, false>(S, lds, p.o, p.d, 0.0, tri, t);
-            alive = shade_bounce<kLds>(S, lds, p, tri, t, n_shadow) && p.depth < max_depth;
+            trace<kScene, false>(S, lds, p.o, p.d, 0.0, tri, t);
+            alive = shade_bounce<kScene>(S, lds, p, tri, t, n_shadow) && p.depth < max_depth;
             if (!alive) {
                 acc_r += radiance_to_fixed(p.rad.x);
                 acc_g += radiance_to_fixed(p.rad.y);
@@ -194,12 +197,12 @@ __global__ void k_wf_generate(DevScene S, uint32_t s_begin, uint64_t first, uint
 }
 
 // ComputeIntersections (gpu_path_tracer/CudaPathTrace.cu:64-78)
-template <bool kLds>
+template <int kScene>
 __global__ void __launch_bounds__(256)
 k_wf_extend(DevScene S, WfQueue q, const uint32_t* __restrict__ live_count, int2* __restrict__ hits,
             unsigned long long* __restrict__ stats) {
     extern __shared__ float4 lds[];
-    if constexpr (kLds) stage_scene_lds(S, lds);
+    if constexpr (kScene != kSceneGlobal) stage_scene_lds(S, lds);
     const uint32_t count = *live_count;
     const uint32_t stride = gridDim.x * blockDim.x;
     uint32_t n_closest = 0;
@@ -209,7 +212,7 @@ k_wf_extend(DevScene S, WfQueue q, const uint32_t* __restrict__ live_count, int2
         double t = (double)kInfinity;
         if (__float_as_uint(b.w) != 0xFFFFFFFFu) {
             ++n_closest;
-            trace<kLds, false>(S, lds, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), 0.0, tri, t);
+            trace<kScene, false>(S, lds, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), 0.0, tri, t);
         }
         hits[i] = make_int2(tri, __float_as_int((float)t));
     }
@@ -220,13 +223,13 @@ k_wf_extend(DevScene S, WfQueue q, const uint32_t* __restrict__ live_count, int2
 // (gpu_path_tracer/CudaPathTrace.cu:80-111, :149-157) in one pass: shade,
 // then either append the survivor to the next queue or add the finished
 // path's radiance to its pixel.
-template <bool kLds>
+template <int kScene>
 __global__ void __launch_bounds__(256)
 k_wf_shade(DevScene S, int max_depth, WfQueue q_in, const int2* __restrict__ hits, const uint32_t* __restrict__ live_in,
            WfQueue q_out, uint32_t* __restrict__ live_out, int64_t* __restrict__ accum,
            unsigned long long* __restrict__ stats) {
     extern __shared__ float4 lds[];
-    if constexpr (kLds) stage_scene_lds(S, lds);
+    if constexpr (kScene != kSceneGlobal) stage_scene_lds(S, lds);
     const uint32_t count = *live_in;
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t lane = threadIdx.x & 63u;
@@ -244,7 +247,7 @@ k_wf_shade(DevScene S, int max_depth, WfQueue q_in, const int2* __restrict__ hit
                 const int2 h = hits[i];
                 // the float conversion of t happens here in the single-kernel
                 // path as well (Ray::operator() narrows t, Ray.hpp:27)
-                keep = shade_bounce<kLds>(S, lds, p, h.x, (double)__int_as_float(h.y), n_shadow) && p.depth < max_depth;
+                keep = shade_bounce<kScene>(S, lds, p, h.x, (double)__int_as_float(h.y), n_shadow) && p.depth < max_depth;
                 if (!keep) accumulate_pixel(accum, p.pixel, p.rad);
             }
         }
@@ -267,6 +270,15 @@ __global__ void k_resolve(const int64_t* __restrict__ accum, size_t n, double de
 }
 
 }  // namespace
+
+// run CALL with kS bound to the scene's traversal variant as a compile-time constant
+#define HPT_DISPATCH_SCENE(variant, CALL)                                         \
+    switch (variant) {                                                            \
+    case kSceneGlobal: { constexpr int kS = kSceneGlobal; CALL; } break;          \
+    case kSceneLds: { constexpr int kS = kSceneLds; CALL; } break;                \
+    case kSceneTiny32: { constexpr int kS = kSceneTiny32; CALL; } break;          \
+    default: { constexpr int kS = kSceneTiny64; CALL; } break;                    \
+    }
 
 // ------------------------------------------------------------------ context --
 
@@ -551,6 +563,13 @@ int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* sc) {
     S.seed = seed;
     const uint64_t f4 = 2ull * nn + 4ull * nt;
     S.lds_float4s = (f4 * 16ull <= kLdsLimit) ? (uint32_t)f4 : 0u;
+    S.variant = !S.lds_float4s ? kSceneGlobal : (nt <= 32 ? kSceneTiny32 : (nt <= 64 ? kSceneTiny64 : kSceneLds));
+    if (const char* e = getenv("HPT_TRACE_VARIANT")) {  // experiments: force a simpler variant
+        const int v = atoi(e);
+        if (v == kSceneGlobal) { S.variant = kSceneGlobal; S.lds_float4s = 0; }
+        else if (v == kSceneLds && S.lds_float4s) S.variant = kSceneLds;
+        else if (v == kSceneTiny64 && S.lds_float4s && nt <= 64) S.variant = kSceneTiny64;
+    }
     ctx->has_scene = true;
     return HPT_OK;
 }
@@ -607,13 +626,10 @@ int hpt_render(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sample
         if (blocks > 0x7FFFFFFFull) return fail(HPT_ERR_INVALID_ARGUMENT, "image too large for block size %d", block);
         for (uint32_t s = sample_begin; s < sample_begin + sample_count;) {
             const uint32_t e = (sample_begin + sample_count - s > ctx->spp_per_launch) ? s + ctx->spp_per_launch : sample_begin + sample_count;
-            if (lds) {
-                if (block <= 256) hipLaunchKernelGGL((k_render_mega<true, 256>), dim3((uint32_t)blocks), dim3(block), lds, stream, S, max_depth, s, e, accum, ctx->d_stats);
-                else hipLaunchKernelGGL((k_render_mega<true, 1024>), dim3((uint32_t)blocks), dim3(block), lds, stream, S, max_depth, s, e, accum, ctx->d_stats);
-            } else {
-                if (block <= 256) hipLaunchKernelGGL((k_render_mega<false, 256>), dim3((uint32_t)blocks), dim3(block), 0, stream, S, max_depth, s, e, accum, ctx->d_stats);
-                else hipLaunchKernelGGL((k_render_mega<false, 1024>), dim3((uint32_t)blocks), dim3(block), 0, stream, S, max_depth, s, e, accum, ctx->d_stats);
-            }
+            HPT_DISPATCH_SCENE(S.variant, {
+                if (block <= 256) hipLaunchKernelGGL((k_render_mega<kS, 256>), dim3((uint32_t)blocks), dim3(block), lds, stream, S, max_depth, s, e, accum, ctx->d_stats);
+                else hipLaunchKernelGGL((k_render_mega<kS, 1024>), dim3((uint32_t)blocks), dim3(block), lds, stream, S, max_depth, s, e, accum, ctx->d_stats);
+            })
             HIP_TRY(hipGetLastError());
             ++launches;
             s = e;
@@ -635,13 +651,10 @@ int hpt_render(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sample
             for (int it = 0; it < max_depth; ++it) {
                 const WfQueue& qi = q[it & 1];
                 const WfQueue& qo = q[(it + 1) & 1];
-                if (lds) {
-                    hipLaunchKernelGGL((k_wf_extend<true>), dim3(grid), dim3(wblock), lds, stream, S, qi, ctx->d_live + it, ctx->d_hits, ctx->d_stats);
-                    hipLaunchKernelGGL((k_wf_shade<true>), dim3(grid), dim3(wblock), lds, stream, S, max_depth, qi, ctx->d_hits, ctx->d_live + it, qo, ctx->d_live + it + 1, accum, ctx->d_stats);
-                } else {
-                    hipLaunchKernelGGL((k_wf_extend<false>), dim3(grid), dim3(wblock), 0, stream, S, qi, ctx->d_live + it, ctx->d_hits, ctx->d_stats);
-                    hipLaunchKernelGGL((k_wf_shade<false>), dim3(grid), dim3(wblock), 0, stream, S, max_depth, qi, ctx->d_hits, ctx->d_live + it, qo, ctx->d_live + it + 1, accum, ctx->d_stats);
-                }
+                HPT_DISPATCH_SCENE(S.variant, {
+                    hipLaunchKernelGGL((k_wf_extend<kS>), dim3(grid), dim3(wblock), lds, stream, S, qi, ctx->d_live + it, ctx->d_hits, ctx->d_stats);
+                    hipLaunchKernelGGL((k_wf_shade<kS>), dim3(grid), dim3(wblock), lds, stream, S, max_depth, qi, ctx->d_hits, ctx->d_live + it, qo, ctx->d_live + it + 1, accum, ctx->d_stats);
+                })
                 HIP_TRY(hipGetLastError());
                 launches += 2;
             }
@@ -685,8 +698,9 @@ int hpt_intersect_batch_dev(hpt_ctx* ctx, size_t n, const float* o_dev, const fl
     const DevScene& S = ctx->S;
     const uint32_t lds = lds_bytes(S);
     const int grid = grid_for(ctx, n, block);
-    if (lds) hipLaunchKernelGGL((k_intersect_batch<true>), dim3(grid), dim3(block), lds, (hipStream_t)stream, S, n, o_dev, d_dev, shadow_dev, tmax_dev, prim_dev, t_dev);
-    else hipLaunchKernelGGL((k_intersect_batch<false>), dim3(grid), dim3(block), 0, (hipStream_t)stream, S, n, o_dev, d_dev, shadow_dev, tmax_dev, prim_dev, t_dev);
+    HPT_DISPATCH_SCENE(S.variant, {
+        hipLaunchKernelGGL((k_intersect_batch<kS>), dim3(grid), dim3(block), lds, (hipStream_t)stream, S, n, o_dev, d_dev, shadow_dev, tmax_dev, prim_dev, t_dev);
+    })
     HIP_TRY(hipGetLastError());
     return HPT_OK;
 }

@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/hpt.h"
 
 namespace hpt {
@@ -159,6 +161,7 @@ struct DevScene {
     int width, height;
     uint32_t seed;
     uint32_t lds_float4s;  // > 0: nodes+tris are staged into LDS (2*num_nodes + 4*num_tris float4)
+    int32_t variant;       // kSceneGlobal .. kSceneTiny64
 };
 
 // Stage the node and triangle records into LDS (tiny scenes: the Cornell box is
@@ -171,20 +174,67 @@ HD void stage_scene_lds(const DevScene& S, float4* lds) {
 }
 
 // ------------------------------------------------------------ traversal -----
+// Scene residency / traversal variant, chosen at upload from the scene size:
+enum {
+    kSceneGlobal = 0,  // records read through L1/L2; triangle tested when its leaf is reached
+    kSceneLds = 1,     // records staged in LDS; same loop
+    kSceneTiny32 = 2,  // LDS, <= 32 triangles: the box walk only *marks* the triangles of the
+    kSceneTiny64 = 3   // leaves it reaches (one bit each, 32- or 64-bit mask per lane); the
+                       // triangle tests run afterwards in a loop of their own, so lanes that
+                       // are at interior nodes never idle through another lane's triangle test
+};
+
+// Bounds3::IntersectP (common/Bounds3.hpp:93-118): float slab test, no t-range
+// culling, every comparison false on NaN.
+HD bool box_hit(const float4 lo, const float4 hi, f3 o, f3 inv, bool nx, bool ny, bool nz) {
+    const float ax = (lo.x - o.x) * inv.x, bx = (hi.x - o.x) * inv.x;
+    const float ay = (lo.y - o.y) * inv.y, by = (hi.y - o.y) * inv.y;
+    const float az = (lo.z - o.z) * inv.z, bz = (hi.z - o.z) * inv.z;
+    float tMin = nx ? bx : ax, tMax = nx ? ax : bx;
+    const float tyMin = ny ? by : ay, tyMax = ny ? ay : by;
+    const float tzMin = nz ? bz : az, tzMax = nz ? az : bz;
+    bool hit = !((tMin > tyMax) || (tyMin > tMax));
+    if (tyMin > tMin) tMin = tyMin;
+    if (tyMax < tMax) tMax = tyMax;
+    return hit && !((tMin > tzMax) || (tzMin > tMax));
+}
+
+// Triangle::getIntersection (common/Triangle.hpp:164-198): back-face cull,
+// float cross/dot products, double det, 1/det, u, v, t.
+HD bool tri_hit(const float4* __restrict__ T, int tri, f3 o, f3 d, double& t_out) {
+    const f3 n = xyz(T[4 * tri + 3]);
+    if (dot(d, n) > 0) return false;
+    const f3 v0 = xyz(T[4 * tri]), e1 = xyz(T[4 * tri + 1]), e2 = xyz(T[4 * tri + 2]);
+    const f3 pvec = cross(d, e2);
+    const float detf = dot(e1, pvec);
+    if (fabsf(detf) < kEpsilon5) return false;
+    const double det_inv = 1. / (double)detf;
+    const f3 tvec = o - v0;
+    const double u = (double)dot(tvec, pvec) * det_inv;
+    if (u < 0 || u > 1) return false;
+    const f3 qvec = cross(tvec, e1);
+    const double v = (double)dot(d, qvec) * det_inv;
+    if (v < 0 || u + v > 1) return false;
+    const double t = (double)dot(e2, qvec) * det_inv;
+    if (t < 0) return false;
+    t_out = t;
+    return true;
+}
+
 // BVHAccel::getIntersection (common/BVH.hpp:91-145) over the flattened tree:
 //   node visited after a box hit  = i + 1        (nextIfHit  = pre-order successor, BVH.cpp:53-62)
 //   node visited after a box miss = miss link    (nextIfMiss, BVH.cpp:22-37)
-// with Bounds3::IntersectP (common/Bounds3.hpp:93-118: float slab test, no
-// t-range culling, NaN comparisons false) and Triangle::getIntersection
-// (common/Triangle.hpp:164-198: float cross/dot products, double det, 1/det,
-// u, v, t).  Closest hit keeps the strict `<` update in visit order
-// (BVH.hpp:130); triangles are stored in visit order, so no tie-break is needed.
-// kShadow: any-hit with t < tmax - Epsilon4 (BVH.hpp:121-127); returns on the first.
-template <bool kLds, bool kShadow>
+// Closest hit keeps the strict `<` update in visit order (BVH.hpp:130);
+// triangles are stored in visit order and the deferred variants test marked
+// triangles in ascending index, so ties resolve exactly as in the reference.
+// kShadow: any-hit with t < tmax - Epsilon4 (BVH.hpp:121-127).  Which triangles
+// are tested is decided by the box tests alone, so deferring the tests changes
+// no result; an occluded shadow ray merely finishes its box walk first.
+template <int kScene, bool kShadow>
 HD void trace(const DevScene& S, const float4* __restrict__ lds, f3 o, f3 d, double tmax, int& hit_tri, double& hit_t) {
     const float4* N;
     const float4* T;
-    if constexpr (kLds) {
+    if constexpr (kScene != kSceneGlobal) {
         N = lds;
         T = lds + 2u * S.num_nodes;
     } else {
@@ -198,60 +248,67 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, f3 o, f3 d, dou
     double best_t = (double)kInfinity;
     int node = 0;
     const int end = (int)S.num_nodes;
-    while (node < end) {
-        const float4 lo = N[2 * node], hi = N[2 * node + 1];
-        const float ax = (lo.x - o.x) * inv.x, bx = (hi.x - o.x) * inv.x;
-        const float ay = (lo.y - o.y) * inv.y, by = (hi.y - o.y) * inv.y;
-        const float az = (lo.z - o.z) * inv.z, bz = (hi.z - o.z) * inv.z;
-        float tMin = nx ? bx : ax, tMax = nx ? ax : bx;
-        const float tyMin = ny ? by : ay, tyMax = ny ? ay : by;
-        const float tzMin = nz ? bz : az, tzMax = nz ? az : bz;
-        bool hit = !((tMin > tyMax) || (tyMin > tMax));
-        if (tyMin > tMin) tMin = tyMin;
-        if (tyMax < tMax) tMax = tyMax;
-        hit = hit && !((tMin > tzMax) || (tzMin > tMax));
-        int next = __float_as_int(lo.w);
-        if (hit) {
-            next = node + 1;
+    if constexpr (kScene == kSceneTiny32 || kScene == kSceneTiny64) {
+        using mask_t = typename std::conditional<kScene == kSceneTiny32, uint32_t, unsigned long long>::type;
+        mask_t pending = 0;
+        while (node < end) {
+            const float4 lo = N[2 * node], hi = N[2 * node + 1];
+            const bool hit = box_hit(lo, hi, o, inv, nx, ny, nz);
             const int tri = __float_as_int(hi.w);
-            if (tri >= 0) {
-                const float4 t3 = T[4 * tri + 3];
-                const f3 n = xyz(t3);
-                if (!(dot(d, n) > 0)) {
-                    const float4 t0 = T[4 * tri], t1 = T[4 * tri + 1], t2 = T[4 * tri + 2];
-                    const f3 v0 = xyz(t0), e1 = xyz(t1), e2 = xyz(t2);
-                    const f3 pvec = cross(d, e2);
-                    const float detf = dot(e1, pvec);
-                    if (!(fabsf(detf) < kEpsilon5)) {
-                        const double det_inv = 1. / (double)detf;
-                        const f3 tvec = o - v0;
-                        const double u = (double)dot(tvec, pvec) * det_inv;
-                        if (!(u < 0 || u > 1)) {
-                            const f3 qvec = cross(tvec, e1);
-                            const double v = (double)dot(d, qvec) * det_inv;
-                            if (!(v < 0 || u + v > 1)) {
-                                const double t = (double)dot(e2, qvec) * det_inv;
-                                if (!(t < 0)) {
-                                    if constexpr (kShadow) {
-                                        if (t < limit) {
-                                            best = tri;
-                                            best_t = t;
-                                            next = end;
-                                        }
-                                    } else {
-                                        if (t < best_t) {
-                                            best = tri;
-                                            best_t = t;
-                                        }
-                                    }
-                                }
-                            }
-                        }
+            if (hit && tri >= 0) pending |= (mask_t)1 << tri;
+            node = hit ? node + 1 : __float_as_int(lo.w);
+        }
+        // cheap filter first: drop back-facing triangles (Triangle.hpp:168-169), so
+        // that the expensive rounds below are only as many as the busiest lane needs
+        for (mask_t m = pending; m;) {
+            const int tri = (kScene == kSceneTiny32) ? __ffs((int)m) - 1 : __ffsll((long long)m) - 1;
+            m &= m - 1;
+            if (dot(d, xyz(T[4 * tri + 3])) > 0) pending &= ~((mask_t)1 << tri);
+        }
+        while (pending) {
+            const int tri = (kScene == kSceneTiny32) ? __ffs((int)pending) - 1 : __ffsll((long long)pending) - 1;
+            pending &= pending - 1;
+            double t;
+            if (tri_hit(T, tri, o, d, t)) {
+                if constexpr (kShadow) {
+                    if (t < limit) {
+                        best = tri;
+                        best_t = t;
+                        pending = 0;
+                    }
+                } else {
+                    if (t < best_t) {
+                        best = tri;
+                        best_t = t;
                     }
                 }
             }
         }
-        node = next;
+    } else {
+        while (node < end) {
+            const float4 lo = N[2 * node], hi = N[2 * node + 1];
+            int next = __float_as_int(lo.w);
+            if (box_hit(lo, hi, o, inv, nx, ny, nz)) {
+                next = node + 1;
+                const int tri = __float_as_int(hi.w);
+                double t;
+                if (tri >= 0 && tri_hit(T, tri, o, d, t)) {
+                    if constexpr (kShadow) {
+                        if (t < limit) {
+                            best = tri;
+                            best_t = t;
+                            next = end;
+                        }
+                    } else {
+                        if (t < best_t) {
+                            best = tri;
+                            best_t = t;
+                        }
+                    }
+                }
+            }
+            node = next;
+        }
     }
     hit_tri = best;
     hit_t = best_t;
@@ -402,7 +459,7 @@ HD void generate_camera_path(const DevScene& S, uint32_t pixel, uint32_t sample,
 // (hit_tri, hit_t); hit_tri < 0 = miss.  Returns false when the path ends on
 // this bounce for the reason "missed the scene" (remainingBounces = 0, :156-161);
 // the caller ends it after max_depth bounces otherwise.  Counts shadow queries.
-template <bool kLds>
+template <int kScene>
 HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, Path& p, int hit_tri, double hit_t,
                      uint32_t& shadow_queries) {
     bool alive = true;
@@ -411,7 +468,7 @@ HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, Path& p,
             alive = false;
             break;
         }
-        const float4* T = kLds ? lds + 2u * S.num_nodes : S.tris;
+        const float4* T = (kScene != kSceneGlobal) ? lds + 2u * S.num_nodes : S.tris;
         const float4 t0 = T[4 * hit_tri], t1 = T[4 * hit_tri + 1], t3 = T[4 * hit_tri + 3];
         const f3 normal = xyz(t3);
         const float triangleArea = t0.w;
@@ -479,7 +536,7 @@ HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, Path& p,
                 int occ_tri;
                 double occ_t;
                 ++shadow_queries;
-                trace<kLds, true>(S, lds, so, wi, (double)length(px), occ_tri, occ_t);
+                trace<kScene, true>(S, lds, so, wi, (double)length(px), occ_tri, occ_t);
                 if (occ_tri < 0) {
                     f3 bsdf;
                     float bsdfPdf;
