@@ -95,42 +95,70 @@ __device__ __forceinline__ void accumulate_pixel(int64_t* accum, uint32_t pixel,
 #ifndef HPT_MEGA_WAVES
 #define HPT_MEGA_WAVES 1
 #endif
+// Mode 1.  One wave owns one 8x8 pixel tile and traces `s_count` samples of each
+// of its pixels.  The tile's (pixel, sample) work items form a pool that the
+// lanes draw from: a lane whose path has ended takes the next item (ballot +
+// prefix count, no atomics), so all 64 lanes stay busy until the pool is empty
+// although path lengths vary from 1 to max_depth bounces.  Finished paths add
+// their fixed-point radiance to per-wave LDS accumulators (any lane may finish
+// any pixel of the tile); the tile is added to the global buffer once at the end.
 template <int kScene, int kMaxBlock>
 __global__ void __launch_bounds__(kMaxBlock, (kMaxBlock == 256 ? HPT_MEGA_WAVES : 1))
-k_render_mega(DevScene S, int max_depth, uint32_t s_begin, uint32_t s_end, int64_t* __restrict__ accum,
+k_render_mega(DevScene S, int max_depth, uint32_t s_begin, uint32_t s_count, int64_t* __restrict__ accum,
               unsigned long long* __restrict__ stats) {
     extern __shared__ float4 lds[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t waves_per_block = (blockDim.x + 63u) >> 6;
+    const uint32_t wave_lanes = min(64u, blockDim.x - wave * 64u);  // the last wave of an odd-sized block is partial
+    unsigned long long* tile_acc = reinterpret_cast<unsigned long long*>(lds + S.lds_float4s) + wave * 192u;
+    for (uint32_t i = lane; i < 192u; i += wave_lanes) tile_acc[i] = 0ull;
     if constexpr (kScene != kSceneGlobal) stage_scene_lds(S, lds);
-    uint32_t pixel;
-    const bool valid = lane_to_pixel(S, blockIdx.x * blockDim.x + threadIdx.x, pixel);
+
+    const uint32_t W = (uint32_t)S.width, H = (uint32_t)S.height;
+    const uint32_t tiles_x = (W + 7u) >> 3, tiles_y = (H + 7u) >> 3;
+    const uint32_t tile = blockIdx.x * waves_per_block + wave;  // wave-uniform
     uint32_t n_closest = 0, n_shadow = 0, n_paths = 0;
-    if (valid) {
-        long long acc_r = 0, acc_g = 0, acc_b = 0;
-        uint32_t s = s_begin;
+    if (tile < tiles_x * tiles_y) {
+        const uint32_t x0 = (tile % tiles_x) * 8u, y0 = (tile / tiles_x) * 8u;
+        const uint32_t vw = min(8u, W - x0), vh = min(8u, H - y0), nv = vw * vh;  // pixels of an edge tile
+        const uint32_t total = nv * s_count;
+        uint32_t next = 0;  // same value in every lane
+        uint32_t slot = 0;
         bool alive = false;
         Path p;
-        while (alive || s < s_end) {
-            if (!alive) {
-                generate_camera_path(S, pixel, s, p);
-                ++s;
-                ++n_paths;
-                alive = true;
+        for (;;) {
+            const unsigned long long need = __ballot(!alive);
+            if (need) {
+                const uint32_t k = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+                next += (uint32_t)__popcll(need);
+                if (!alive && k < total) {
+                    slot = k % nv;
+                    generate_camera_path(S, (y0 + slot / vw) * W + x0 + slot % vw, s_begin + k / nv, p);
+                    ++n_paths;
+                    alive = true;
+                }
             }
-            int tri;
-            double t;
-            ++n_closest;
-            trace<kScene, false>(S, lds, p.o, p.d, 0.0, tri, t);
-            alive = shade_bounce<kScene>(S, lds, p, tri, t, n_shadow) && p.depth < max_depth;
-            if (!alive) {
-                acc_r += radiance_to_fixed(p.rad.x);
-                acc_g += radiance_to_fixed(p.rad.y);
-                acc_b += radiance_to_fixed(p.rad.z);
+            if (!__ballot(alive)) break;
+            if (alive) {
+                int tri;
+                double t;
+                ++n_closest;
+                trace<kScene, false>(S, lds, p.o, p.d, 0.0, tri, t);
+                alive = shade_bounce<kScene>(S, lds, p, tri, t, n_shadow) && p.depth < max_depth;
+                if (!alive) {
+                    atomicAdd(tile_acc + 3u * slot + 0u, (unsigned long long)radiance_to_fixed(p.rad.x));
+                    atomicAdd(tile_acc + 3u * slot + 1u, (unsigned long long)radiance_to_fixed(p.rad.y));
+                    atomicAdd(tile_acc + 3u * slot + 2u, (unsigned long long)radiance_to_fixed(p.rad.z));
+                }
             }
         }
-        unsigned long long* a = reinterpret_cast<unsigned long long*>(accum) + 3ull * pixel;
-        atomicAdd(a + 0, (unsigned long long)acc_r);
-        atomicAdd(a + 1, (unsigned long long)acc_g);
-        atomicAdd(a + 2, (unsigned long long)acc_b);
+        unsigned long long* out = reinterpret_cast<unsigned long long*>(accum);
+        for (uint32_t j = lane; j < nv; j += wave_lanes) {
+            const unsigned long long pix = (unsigned long long)(y0 + j / vw) * W + x0 + j % vw;
+            atomicAdd(out + 3ull * pix + 0ull, tile_acc[3u * j + 0u]);
+            atomicAdd(out + 3ull * pix + 1ull, tile_acc[3u * j + 1u]);
+            atomicAdd(out + 3ull * pix + 2ull, tile_acc[3u * j + 2u]);
+        }
     }
     atomicAdd(stats + kStatClosest, (unsigned long long)n_closest);
     atomicAdd(stats + kStatShadow, (unsigned long long)n_shadow);
@@ -311,7 +339,7 @@ struct hpt_ctx {
     std::vector<hipEvent_t> free_events;
     double kernel_ms = 0.0;
     uint32_t launches = 0;
-    uint32_t spp_per_launch = 64;
+    uint32_t spp_per_launch = 256;  // samples per pixel per single-kernel launch (HPT_SPP_PER_LAUNCH)
 };
 
 namespace {
@@ -622,17 +650,18 @@ int hpt_render(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sample
     uint32_t launches = 0;
 
     if (mode == HPT_MODE_SINGLE_KERNEL) {
-        const uint64_t blocks = (lanes + (uint64_t)block - 1) / (uint64_t)block;
-        if (blocks > 0x7FFFFFFFull) return fail(HPT_ERR_INVALID_ARGUMENT, "image too large for block size %d", block);
+        const uint32_t waves_per_block = ((uint32_t)block + 63u) >> 6;
+        const uint32_t blocks = (tiles + waves_per_block - 1u) / waves_per_block;
+        const uint32_t lds_mega = lds + waves_per_block * 192u * 8u;  // + per-wave tile accumulators
         for (uint32_t s = sample_begin; s < sample_begin + sample_count;) {
-            const uint32_t e = (sample_begin + sample_count - s > ctx->spp_per_launch) ? s + ctx->spp_per_launch : sample_begin + sample_count;
+            const uint32_t n = (sample_begin + sample_count - s > ctx->spp_per_launch) ? ctx->spp_per_launch : sample_begin + sample_count - s;
             HPT_DISPATCH_SCENE(S.variant, {
-                if (block <= 256) hipLaunchKernelGGL((k_render_mega<kS, 256>), dim3((uint32_t)blocks), dim3(block), lds, stream, S, max_depth, s, e, accum, ctx->d_stats);
-                else hipLaunchKernelGGL((k_render_mega<kS, 1024>), dim3((uint32_t)blocks), dim3(block), lds, stream, S, max_depth, s, e, accum, ctx->d_stats);
+                if (block <= 256) hipLaunchKernelGGL((k_render_mega<kS, 256>), dim3(blocks), dim3(block), lds_mega, stream, S, max_depth, s, n, accum, ctx->d_stats);
+                else hipLaunchKernelGGL((k_render_mega<kS, 1024>), dim3(blocks), dim3(block), lds_mega, stream, S, max_depth, s, n, accum, ctx->d_stats);
             })
             HIP_TRY(hipGetLastError());
             ++launches;
-            s = e;
+            s += n;
         }
     } else {
         // the wavefront kernels are built for workgroups of up to 256 lanes
