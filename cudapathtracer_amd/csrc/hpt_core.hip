@@ -71,7 +71,7 @@ __global__ void k_intersect_batch(DevScene S, size_t n, const float* __restrict_
                                   const uint8_t* __restrict__ shadow, const double* __restrict__ tmax,
                                   int32_t* __restrict__ prim, double* __restrict__ t_out) {
     extern __shared__ float4 lds[];
-    if constexpr (kScene != kSceneGlobal) stage_scene_lds(S, lds);
+    if constexpr (kScene != kSceneGlobal) stage_scene_lds<kScene == kSceneTiny32>(S, lds);
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) {
         const f3 ro = mk(o[3 * r], o[3 * r + 1], o[3 * r + 2]);
@@ -112,7 +112,7 @@ k_render_mega(DevScene S, int max_depth, uint32_t s_begin, uint32_t s_count, int
     const uint32_t wave_lanes = min(64u, blockDim.x - wave * 64u);  // the last wave of an odd-sized block is partial
     unsigned long long* tile_acc = reinterpret_cast<unsigned long long*>(lds + S.lds_float4s) + wave * 192u;
     for (uint32_t i = lane; i < 192u; i += wave_lanes) tile_acc[i] = 0ull;
-    if constexpr (kScene != kSceneGlobal) stage_scene_lds(S, lds);
+    if constexpr (kScene != kSceneGlobal) stage_scene_lds<kScene == kSceneTiny32>(S, lds);
 
     const uint32_t W = (uint32_t)S.width, H = (uint32_t)S.height;
     const uint32_t tiles_x = (W + 7u) >> 3, tiles_y = (H + 7u) >> 3;
@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(256)
 k_wf_extend(DevScene S, WfQueue q, const uint32_t* __restrict__ live_count, int2* __restrict__ hits,
             unsigned long long* __restrict__ stats) {
     extern __shared__ float4 lds[];
-    if constexpr (kScene != kSceneGlobal) stage_scene_lds(S, lds);
+    if constexpr (kScene != kSceneGlobal) stage_scene_lds<kScene == kSceneTiny32>(S, lds);
     const uint32_t count = *live_count;
     const uint32_t stride = gridDim.x * blockDim.x;
     uint32_t n_closest = 0;
@@ -257,7 +257,7 @@ k_wf_shade(DevScene S, int max_depth, WfQueue q_in, const int2* __restrict__ hit
            WfQueue q_out, uint32_t* __restrict__ live_out, int64_t* __restrict__ accum,
            unsigned long long* __restrict__ stats) {
     extern __shared__ float4 lds[];
-    if constexpr (kScene != kSceneGlobal) stage_scene_lds(S, lds);
+    if constexpr (kScene != kSceneGlobal) stage_scene_lds<kScene == kSceneTiny32>(S, lds);
     const uint32_t count = *live_in;
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t lane = threadIdx.x & 63u;
@@ -320,8 +320,8 @@ struct hpt_ctx {
     float* d_node_area = nullptr;
     float4* d_tris = nullptr;
     float4* d_tri_v12 = nullptr;
-    hpt_material* d_mats = nullptr;
-    hpt_light* d_lights = nullptr;
+    DevMaterial* d_mats = nullptr;
+    DevLight* d_lights = nullptr;
     // accumulation + stats
     int64_t* d_accum = nullptr;
     size_t accum_elems = 0;
@@ -553,14 +553,63 @@ int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* sc) {
     HIP_TRY(hipMalloc((void**)&ctx->d_node_area, nn * 4));
     HIP_TRY(hipMalloc((void**)&ctx->d_tris, nt * 64));
     HIP_TRY(hipMalloc((void**)&ctx->d_tri_v12, nt * 32));
-    HIP_TRY(hipMalloc((void**)&ctx->d_mats, sc->num_materials * sizeof(hpt_material)));
-    HIP_TRY(hipMalloc((void**)&ctx->d_lights, (sc->num_lights ? sc->num_lights : 1) * sizeof(hpt_light)));
+    HIP_TRY(hipMalloc((void**)&ctx->d_mats, sc->num_materials * sizeof(DevMaterial)));
+    HIP_TRY(hipMalloc((void**)&ctx->d_lights, (sc->num_lights ? sc->num_lights : 1) * sizeof(DevLight)));
     HIP_TRY(hipMemcpy(ctx->d_nodes, sc->nodes, nn * 32, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->d_node_area, sc->node_area, nn * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(ctx->d_tris, sc->tris, nt * 64, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->d_tri_v12, sc->tri_v12, nt * 32, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(ctx->d_mats, sc->materials, sc->num_materials * sizeof(hpt_material), hipMemcpyHostToDevice));
-    if (sc->num_lights) HIP_TRY(hipMemcpy(ctx->d_lights, sc->lights, sc->num_lights * sizeof(hpt_light), hipMemcpyHostToDevice));
+    {
+        // derived tables (see DevMaterial / DevLight); plain float arithmetic in the
+        // reference's order, this file is compiled without FMA contraction
+        const float pi = 3.1415926535897932384626422832795028841971f;
+        auto lum = [](const float* c) {  // Math::luminance, common/MathUtils.hpp:218-222
+            const float tx = c[0] * .2126f, ty = c[1] * .7152f, tz = c[2] * .0722f;
+            return tx + ty + tz;
+        };
+        std::vector<DevMaterial> mats(sc->num_materials);
+        for (uint32_t i = 0; i < sc->num_materials; ++i) {
+            const hpt_material& m = sc->materials[i];
+            DevMaterial& d = mats[i];
+            std::memset(&d, 0, sizeof d);
+            d.type = m.type;
+            const float ee = (m.emission[0] * m.emission[0] + m.emission[1] * m.emission[1]) + m.emission[2] * m.emission[2];
+            const bool specular = (m.type == 1 && std::sqrt(m.roughness) < 1e-3f) || m.type == 2;  // Material.hpp:151-162
+            d.flags = (ee > 0.0f ? kMatEmitting : 0u) | (specular ? kMatSpecular : 0u);
+            for (int c = 0; c < 3; ++c) {
+                d.emission[c] = m.emission[c];
+                d.albedo[c] = m.albedo[c];
+                d.albedo_over_pi[c] = (m.albedo[c] * 1.f) / pi;
+                d.f0[c] = 0.04f * (1.0f - m.metallic) + m.albedo[c] * m.metallic;  // Math::lerp, MathUtils.hpp:182-184
+            }
+            d.metallic = m.metallic;
+            d.one_minus_metallic = 1.0f - m.metallic;
+            d.roughness = m.roughness;
+            d.rsq = m.roughness * m.roughness;
+            d.rsq_minus_1 = d.rsq - 1.0f;
+        }
+        std::vector<DevLight> lights(sc->num_lights ? sc->num_lights : 1);
+        std::memset(lights.data(), 0, lights.size() * sizeof(DevLight));
+        for (uint32_t i = 0; i < sc->num_lights; ++i) {
+            const hpt_light& l = sc->lights[i];
+            DevLight& d = lights[i];
+            d.area = l.area;
+            d.root_area = l.root_area;
+            d.inv_root_area = 1.0f / l.root_area;
+            d.root_node = l.root_node;
+            for (int c = 0; c < 3; ++c) d.emission[c] = sc->materials[l.material].emission[c];
+        }
+        std::vector<float> tris(sc->tris, sc->tris + nt * 16);
+        for (size_t t = 0; t < nt; ++t) {
+            int32_t mat;
+            std::memcpy(&mat, &tris[16 * t + 7], 4);
+            const float area = tris[16 * t + 3];
+            // luminance(Le) * 2 * pi * triangleArea / sumLightPower (common/Scene.hpp:179, :215)
+            tris[16 * t + 3] = lum(sc->materials[mat].emission) * 2.f * pi * area / sc->sum_light_power;
+        }
+        HIP_TRY(hipMemcpy(ctx->d_tris, tris.data(), nt * 64, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ctx->d_mats, mats.data(), mats.size() * sizeof(DevMaterial), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ctx->d_lights, lights.data(), lights.size() * sizeof(DevLight), hipMemcpyHostToDevice));
+    }
     ctx->accum_elems = 3ull * (size_t)sc->width * (size_t)sc->height;
     HIP_TRY(hipMalloc((void**)&ctx->d_accum, ctx->accum_elems * sizeof(int64_t)));
     HIP_TRY(hipMemset(ctx->d_accum, 0, ctx->accum_elems * sizeof(int64_t)));

@@ -148,13 +148,40 @@ HD long long radiance_to_fixed(float v) {
 }
 
 // ---------------------------------------------------------------- scene -----
+// Device-side material / light tables, derived from hpt_material / hpt_light at
+// upload.  The derived members are values the integrator would otherwise
+// recompute at every bounce from constants of the material; they are computed
+// on the host with the same float operations in the same order, so using them
+// changes no result.
+struct DevMaterial {
+    int32_t type;
+    uint32_t flags;            // kMatEmitting | kMatSpecular
+    float emission[3];
+    float albedo[3];
+    float albedo_over_pi[3];   // albedo * 1.f / Pi            (Material.hpp:318)
+    float f0[3];               // lerp(0.04, albedo, metallic)  (Material.hpp:335-336)
+    float metallic, one_minus_metallic, roughness, rsq, rsq_minus_1;
+    float _pad;
+};  // 80 bytes
+enum : uint32_t { kMatEmitting = 1u, kMatSpecular = 2u };
+struct DevLight {
+    float area, root_area, inv_root_area;  // inv_root_area = 1.0f / root_area (BVH.hpp:183)
+    uint32_t root_node;
+    float emission[3];
+    float _pad;
+};  // 32 bytes
+// In the device copy of the triangle records the `area` slot (word 3) holds the
+// triangle's MIS "light pdf" instead:
+//   luminance(emission) * 2 * pi * area / sumLightPower   (Scene.hpp:179, :215)
+// which is the only thing the integrator uses the area for.
+
 struct DevScene {
     const float4* nodes;      // 2 x float4 per node: (pMin, miss link) (pMax, triangle | -1)
     const float* node_area;
     const float4* tris;       // 4 x float4 per triangle
     const float4* tri_v12;    // 2 x float4 per triangle
-    const hpt_material* mats;
-    const hpt_light* lights;
+    const DevMaterial* mats;
+    const DevLight* lights;
     uint32_t num_nodes, num_tris, num_mats, num_lights;
     float sum_light_area, sum_light_power;
     float cam_x, cam_y, cam_z, cam_scale, aspect;
@@ -166,9 +193,17 @@ struct DevScene {
 
 // Stage the node and triangle records into LDS (tiny scenes: the Cornell box is
 // 63 nodes + 32 triangles = 4 KiB).  Every thread of the workgroup must call it.
+template <bool kLeafBits>
 HD void stage_scene_lds(const DevScene& S, float4* lds) {
     const uint32_t nn = 2u * S.num_nodes, nt = 4u * S.num_tris;
-    for (uint32_t i = threadIdx.x; i < nn; i += blockDim.x) lds[i] = S.nodes[i];
+    for (uint32_t i = threadIdx.x; i < nn; i += blockDim.x) {
+        float4 v = S.nodes[i];
+        if (kLeafBits && (i & 1u)) {  // pMax half: triangle index -> its bit in the pending mask (0 = interior)
+            const int tri = __float_as_int(v.w);
+            v.w = __uint_as_float(tri >= 0 ? 1u << tri : 0u);
+        }
+        lds[i] = v;
+    }
     for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) lds[nn + i] = S.tris[i];
     __syncthreads();
 }
@@ -197,6 +232,19 @@ HD bool box_hit(const float4 lo, const float4 hi, f3 o, f3 inv, bool nx, bool ny
     if (tyMin > tMin) tMin = tyMin;
     if (tyMax < tMax) tMax = tyMax;
     return hit && !((tMin > tzMax) || (tzMin > tMax));
+}
+
+// The same predicate for rays whose three reciprocal direction components are
+// finite: then no product can be NaN and near <= far holds per axis, so
+// near = min(a, b), far = max(a, b) equal the sign-selected values and the
+// reference's sequence of comparisons reduces to max(near) <= min(far).
+HD bool box_hit_finite(const float4 lo, const float4 hi, f3 o, f3 inv) {
+    const float ax = (lo.x - o.x) * inv.x, bx = (hi.x - o.x) * inv.x;
+    const float ay = (lo.y - o.y) * inv.y, by = (hi.y - o.y) * inv.y;
+    const float az = (lo.z - o.z) * inv.z, bz = (hi.z - o.z) * inv.z;
+    const float tnear = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    const float tfar = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    return tnear <= tfar;
 }
 
 // Triangle::getIntersection (common/Triangle.hpp:164-198): back-face cull,
@@ -251,12 +299,31 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, f3 o, f3 d, dou
     if constexpr (kScene == kSceneTiny32 || kScene == kSceneTiny64) {
         using mask_t = typename std::conditional<kScene == kSceneTiny32, uint32_t, unsigned long long>::type;
         mask_t pending = 0;
-        while (node < end) {
-            const float4 lo = N[2 * node], hi = N[2 * node + 1];
-            const bool hit = box_hit(lo, hi, o, inv, nx, ny, nz);
-            const int tri = __float_as_int(hi.w);
-            if (hit && tri >= 0) pending |= (mask_t)1 << tri;
-            node = hit ? node + 1 : __float_as_int(lo.w);
+        const float kInf = __builtin_inff();
+        if (fabsf(inv.x) < kInf && fabsf(inv.y) < kInf && fabsf(inv.z) < kInf) {
+            while (node < end) {
+                const float4 lo = N[2 * node], hi = N[2 * node + 1];
+                const bool hit = box_hit_finite(lo, hi, o, inv);
+                if constexpr (kScene == kSceneTiny32) {
+                    pending |= hit ? __float_as_uint(hi.w) : 0u;  // staged as a leaf bit
+                } else {
+                    const int tri = __float_as_int(hi.w);
+                    if (hit && tri >= 0) pending |= (mask_t)1 << tri;
+                }
+                node = hit ? node + 1 : __float_as_int(lo.w);
+            }
+        } else {  // a direction component is 0 (or denormal): the reference's NaN-aware sequence
+            while (node < end) {
+                const float4 lo = N[2 * node], hi = N[2 * node + 1];
+                const bool hit = box_hit(lo, hi, o, inv, nx, ny, nz);
+                if constexpr (kScene == kSceneTiny32) {
+                    pending |= hit ? __float_as_uint(hi.w) : 0u;
+                } else {
+                    const int tri = __float_as_int(hi.w);
+                    if (hit && tri >= 0) pending |= (mask_t)1 << tri;
+                }
+                node = hit ? node + 1 : __float_as_int(lo.w);
+            }
         }
         // cheap filter first: drop back-facing triangles (Triangle.hpp:168-169), so
         // that the expensive rounds below are only as many as the busiest lane needs
@@ -349,44 +416,15 @@ HD float powerHeuristic(float f, float g) {
 }
 HD float luminance(f3 c) { return dot(c, mk(.2126f, .7152f, .0722f)); }
 
-// common/Material.hpp:48-80, :100-102
-HD float ggx_distribution(float ndm, float roughness_sq) {
-    const float ndm_sq = ndm * ndm;
-    float denominator = ndm_sq * (roughness_sq - 1.0f) + 1.0f;
-    denominator = kPi * denominator * denominator;
-    return roughness_sq / denominator;
-}
-HD float ggx_geometry(float nl, float nv, float roughness) {
-    return 2.0f / lerp(fabsf(2 * nl * nv), fabsf(nl + nv), roughness);
-}
 HD f3 reflect(f3 ray_in_dir, f3 normal) { return ray_in_dir - dot(ray_in_dir, normal) * normal * 2.f; }  // :6-8
 
-struct Mat {
-    int type;
-    f3 emission, albedo;
-    float metallic, roughness;
-};
-HD Mat load_material(const DevScene& S, int idx) {
-    const hpt_material& m = S.mats[idx];
-    Mat r;
-    r.type = m.type;
-    r.emission = mk(m.emission[0], m.emission[1], m.emission[2]);
-    r.albedo = mk(m.albedo[0], m.albedo[1], m.albedo[2]);
-    r.metallic = m.metallic;
-    r.roughness = m.roughness;
-    return r;
-}
-HD bool mat_emitting(const Mat& m) { return dot(m.emission, m.emission) > 0.0f; }  // Material.hpp:144-146
-HD bool mat_has_specular(const Mat& m) {                                              // :151-162
-    return (m.type == 1 && sqrtf(m.roughness) < 1e-3f) || m.type == 2;
-}
 // Material::pdf and Material::bsdf (Material.hpp:257-276, :315-347), Lambertian and
 // MetallicWorkflow, evaluated together because the integrator always needs both.
-HD void mat_eval(const Mat& m, f3 src, f3 out, f3 normal, f3& bsdf, float& pdf) {
+HD void mat_eval(const DevMaterial& m, f3 src, f3 out, f3 normal, f3& bsdf, float& pdf) {
     if (m.type == 0) {
         const bool front = dot(out, normal) > 0.0f;
         pdf = front ? 0.5f * 1.f / kPi : 0.0f;
-        bsdf = front ? m.albedo * 1.f / kPi : mk(0.0f);
+        bsdf = front ? mk(m.albedo_over_pi[0], m.albedo_over_pi[1], m.albedo_over_pi[2]) : mk(0.0f);
         return;
     }
     const float nds = dot(normal, src), ndo = dot(normal, out);
@@ -399,24 +437,25 @@ HD void mat_eval(const Mat& m, f3 src, f3 out, f3 normal, f3& bsdf, float& pdf) 
     const f3 mm = normalize(src + out);
     const float ndm = dot(normal, mm);
     const float mdo = dot(mm, out);
-    const float rsq = m.roughness * m.roughness;
     const float andm = fabsf(ndm);
-    const float jac = mdo == 0.0f ? 0.0f : 1.0f / (4 * fabsf(mdo));
-    pdf = (ggx_distribution(andm, rsq) * andm) * jac;
-    const float D = ggx_distribution(ndm, rsq);
-    const float G = ggx_geometry(nds, ndo, m.roughness);
-    const f3 f0 = lerp(mk(0.04f), m.albedo, m.metallic);
+    // Microfacet::distribution (:48-53); |ndm|^2 == ndm^2, so D of pdf and bsdf are one value
+    float denominator = (ndm * ndm) * m.rsq_minus_1 + 1.0f;
+    denominator = kPi * denominator * denominator;
+    const float D = m.rsq / denominator;
+    const float jac = mdo == 0.0f ? 0.0f : 1.0f / (4 * fabsf(mdo));  // reflect_jacobian (:100-102)
+    pdf = (D * andm) * jac;
+    const float G = 2.0f / lerp(fabsf(2 * nds * ndo), fabsf(nds + ndo), m.roughness);  // geometry (:59-61)
+    const f3 f0 = mk(m.f0[0], m.f0[1], m.f0[2]);
     const f3 F = f0 + (mk(1.0f) - f0) * pow5(1.0f - mdo);
-    const f3 kd = (mk(1.0f) - F) * (1.0f - m.metallic);
-    const f3 diffuse = kd * m.albedo * 1.f / kPi;
+    const f3 kd = (mk(1.0f) - F) * m.one_minus_metallic;
+    const f3 diffuse = kd * mk(m.albedo[0], m.albedo[1], m.albedo[2]) / kPi;  // "* 1.f" of PiInv is exact
     const f3 specular = D * F * G / 4.0f;
     bsdf = diffuse + specular;
 }
 // Material::sample (Material.hpp:186-199); r0/r1 are draws kSlotBsdf0/1
-HD f3 mat_sample(const Mat& m, float r0, float r1, f3 ray_out_dir, f3 normal) {
+HD f3 mat_sample(const DevMaterial& m, float r0, float r1, f3 ray_out_dir, f3 normal) {
     if (m.type == 0) return sampleHemisphereCosine(normal, r0, r1);
-    const float rsq = m.roughness * m.roughness;
-    const float theta = portable_acos(sqrtf((1.0f - r0) / ((rsq - 1.0f) * r0 + 1.0f)));
+    const float theta = portable_acos(sqrtf((1.0f - r0) / (m.rsq_minus_1 * r0 + 1.0f)));
     const float phi = 2 * kPi * r1;
     float st, ct, sp, cp;
     portable_sincos(theta, st, ct);
@@ -468,37 +507,32 @@ HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, Path& p,
             alive = false;
             break;
         }
-        const float4* T = (kScene != kSceneGlobal) ? lds + 2u * S.num_nodes : S.tris;
-        const float4 t0 = T[4 * hit_tri], t1 = T[4 * hit_tri + 1], t3 = T[4 * hit_tri + 3];
+        // the device copies in global memory (not the LDS stage): word 3 = light pdf
+        const float4 t0 = S.tris[4 * hit_tri], t1 = S.tris[4 * hit_tri + 1], t3 = S.tris[4 * hit_tri + 3];
         const f3 normal = xyz(t3);
-        const float triangleArea = t0.w;
-        const Mat material = load_material(S, __float_as_int(t1.w));
+        const DevMaterial& material = S.mats[__float_as_int(t1.w)];
         const f3 coords = p.o + p.d * (float)hit_t;  // Ray::operator(), Ray.hpp:27
 
-        if (mat_emitting(material)) {  // :164-184
+        if (material.flags & kMatEmitting) {  // :164-184
+            const f3 radiance = mk(material.emission[0], material.emission[1], material.emission[2]);
             if (p.depth == 0 || p.specular) {
-                p.rad = p.rad + p.thr * material.emission;
+                p.rad = p.rad + p.thr * radiance;
             } else {
-                const f3 radiance = material.emission;
-                const float lightPdf = luminance(radiance) * 2.f * kPi * triangleArea / S.sum_light_power;
-                const float weight = powerHeuristic(p.pdf, lightPdf);
+                const float weight = powerHeuristic(p.pdf, t0.w);
                 p.rad = p.rad + p.thr * radiance * weight;
             }
         }
 
-        const u4 ra = philox4x32_10((uint32_t)p.depth, 0u, S.seed, 0u, p.pixel, p.sample);
-        const u4 rb = philox4x32_10((uint32_t)p.depth, 1u, S.seed, 0u, p.pixel, p.sample);
-
         if (!p.specular) {  // :192-228
             // Scene::sampleLight (:99-120)
-            float lightSamplePdf = 0.0f;
+            const u4 ra = philox4x32_10((uint32_t)p.depth, 0u, S.seed, 0u, p.pixel, p.sample);
+            float lightSamplePdf = 0.0f, lightPdf = 0.0f;
             f3 lx = mk(0.f), ln = mk(0.f), lemit = mk(0.f);
-            float larea = 0.f;
             {
                 const float pick = u01(ra.x) * S.sum_light_area;
                 float emit_area_sum = 0;
                 for (uint32_t k = 0; k < S.num_lights; ++k) {
-                    const hpt_light L = S.lights[k];
+                    const DevLight& L = S.lights[k];
                     emit_area_sum += L.area;
                     if (pick <= emit_area_sum) {
                         // BVHAccel::Sample / getSample (BVH.hpp:147-184)
@@ -520,10 +554,9 @@ HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, Path& p,
                         const float4 b1 = S.tri_v12[2 * tri], b2 = S.tri_v12[2 * tri + 1];
                         lx = xyz(a0) * (1.0f - sx) + xyz(b1) * (sx * (1.0f - sy)) + xyz(b2) * (sx * sy);
                         ln = xyz(a3);
-                        larea = a0.w;
-                        lightSamplePdf = 1.0f / L.root_area;
-                        const hpt_material& lm = S.mats[L.material];
-                        lemit = mk(lm.emission[0], lm.emission[1], lm.emission[2]);
+                        lightPdf = a0.w;
+                        lightSamplePdf = L.inv_root_area;
+                        lemit = mk(L.emission[0], L.emission[1], L.emission[2]);
                         break;
                     }
                 }
@@ -544,7 +577,6 @@ HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, Path& p,
                     const float cos_theta = satDot(normal, wi);
                     const float cos_theta_prime = satDot(ln, -wi);
                     const float r2 = dot(lx - coords, lx - coords);
-                    const float lightPdf = luminance(lemit) * 2.f * kPi * larea / S.sum_light_power;
                     const float weight = powerHeuristic(lightPdf, bsdfPdf);
                     p.rad = p.rad + p.thr * lemit * bsdf * cos_theta * cos_theta_prime / r2 / lightSamplePdf * weight;
                 }
@@ -552,6 +584,7 @@ HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, Path& p,
         }
 
         // :230-250
+        const u4 rb = philox4x32_10((uint32_t)p.depth, 1u, S.seed, 0u, p.pixel, p.sample);
         const f3 wo = -p.d;
         const f3 wi = mat_sample(material, u01(rb.x), u01(rb.y), wo, normal);
         f3 bsdf;
@@ -559,7 +592,7 @@ HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, Path& p,
         mat_eval(material, wi, wo, normal, bsdf, pdf);
         p.pdf = pdf;
         if (pdf < kEpsilon5) break;  // the path keeps its ray and re-traces it (:238-240)
-        p.specular = mat_has_specular(material);
+        p.specular = (material.flags & kMatSpecular) != 0;
         const float cos_theta = absDot(normal, wi);
         p.thr = p.thr * (bsdf * cos_theta / pdf);
         p.o = coords + wi * kEpsilon5;
