@@ -73,13 +73,18 @@ __global__ void k_intersect_batch(DevScene S, size_t n, const float* __restrict_
     extern __shared__ float4 lds[];
     if constexpr (kScene != kSceneGlobal) stage_scene_lds<kScene == kSceneTiny32>(S, lds);
     const size_t stride = (size_t)gridDim.x * blockDim.x;
+#ifdef HPT_PROFILE
+    __shared__ unsigned long long prof_dummy[3 * kProfSections];
+    ProfAcc prof;
+    prof.w = prof_dummy;
+#endif
     for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) {
         const f3 ro = mk(o[3 * r], o[3 * r + 1], o[3 * r + 2]);
         const f3 rd = mk(d[3 * r], d[3 * r + 1], d[3 * r + 2]);
         int tri;
         double t;
-        if (shadow && shadow[r]) trace<kScene, true>(S, lds, ro, rd, tmax[r], tri, t);
-        else trace<kScene, false>(S, lds, ro, rd, 0.0, tri, t);
+        if (shadow && shadow[r]) trace<kScene, true>(S, lds, ro, rd, tmax[r], tri, t PROF_PASS);
+        else trace<kScene, false>(S, lds, ro, rd, 0.0, tri, t PROF_PASS);
         prim[r] = tri < 0 ? -1 : __float_as_int(S.tris[4 * tri + 2].w);
         t_out[r] = t;
     }
@@ -126,7 +131,14 @@ k_render_mega(DevScene S, int max_depth, uint32_t s_begin, uint32_t s_count, int
         uint32_t slot = 0;
         bool alive = false;
         Path p;
+#ifdef HPT_PROFILE
+        ProfAcc prof;
+        prof.w = tile_acc + 192u * (waves_per_block - wave) + wave * 3u * kProfSections;  // behind all waves' accumulators
+        for (uint32_t i = lane; i < 3u * kProfSections; i += wave_lanes) prof.w[i] = 0ull;
+        const unsigned long long prof_start = __builtin_readcyclecounter();
+#endif
         for (;;) {
+            PROF_ITER(kProfDone);
             const unsigned long long need = __ballot(!alive);
             if (need) {
                 const uint32_t k = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
@@ -143,8 +155,8 @@ k_render_mega(DevScene S, int max_depth, uint32_t s_begin, uint32_t s_count, int
                 int tri;
                 double t;
                 ++n_closest;
-                trace<kScene, false>(S, lds, p.o, p.d, 0.0, tri, t);
-                alive = shade_bounce<kScene>(S, lds, p, tri, t, n_shadow) && p.depth < max_depth;
+                trace<kScene, false>(S, lds, p.o, p.d, 0.0, tri, t PROF_PASS);
+                alive = shade_bounce<kScene>(S, lds, p, tri, t, n_shadow PROF_PASS) && p.depth < max_depth;
                 if (!alive) {
                     atomicAdd(tile_acc + 3u * slot + 0u, (unsigned long long)radiance_to_fixed(p.rad.x));
                     atomicAdd(tile_acc + 3u * slot + 1u, (unsigned long long)radiance_to_fixed(p.rad.y));
@@ -152,6 +164,11 @@ k_render_mega(DevScene S, int max_depth, uint32_t s_begin, uint32_t s_count, int
                 }
             }
         }
+#ifdef HPT_PROFILE
+        prof_add(prof, kProfDone, __builtin_readcyclecounter() - prof_start);
+        if (lane == 0 && S.prof)
+            for (int i = 0; i < 3 * kProfSections; ++i) atomicAdd(S.prof + i, prof.w[i]);
+#endif
         unsigned long long* out = reinterpret_cast<unsigned long long*>(accum);
         for (uint32_t j = lane; j < nv; j += wave_lanes) {
             const unsigned long long pix = (unsigned long long)(y0 + j / vw) * W + x0 + j % vw;
@@ -240,7 +257,12 @@ k_wf_extend(DevScene S, WfQueue q, const uint32_t* __restrict__ live_count, int2
         double t = (double)kInfinity;
         if (__float_as_uint(b.w) != 0xFFFFFFFFu) {
             ++n_closest;
-            trace<kScene, false>(S, lds, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), 0.0, tri, t);
+#ifdef HPT_PROFILE
+            __shared__ unsigned long long prof_dummy[3 * kProfSections];
+            ProfAcc prof;
+            prof.w = prof_dummy;
+#endif
+            trace<kScene, false>(S, lds, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), 0.0, tri, t PROF_PASS);
         }
         hits[i] = make_int2(tri, __float_as_int((float)t));
     }
@@ -275,7 +297,12 @@ k_wf_shade(DevScene S, int max_depth, WfQueue q_in, const int2* __restrict__ hit
                 const int2 h = hits[i];
                 // the float conversion of t happens here in the single-kernel
                 // path as well (Ray::operator() narrows t, Ray.hpp:27)
-                keep = shade_bounce<kScene>(S, lds, p, h.x, (double)__int_as_float(h.y), n_shadow) && p.depth < max_depth;
+#ifdef HPT_PROFILE
+                __shared__ unsigned long long prof_dummy[3 * kProfSections];
+                ProfAcc prof;
+                prof.w = prof_dummy;
+#endif
+                keep = shade_bounce<kScene>(S, lds, p, h.x, (double)__int_as_float(h.y), n_shadow PROF_PASS) && p.depth < max_depth;
                 if (!keep) accumulate_pixel(accum, p.pixel, p.rad);
             }
         }
@@ -326,6 +353,7 @@ struct hpt_ctx {
     int64_t* d_accum = nullptr;
     size_t accum_elems = 0;
     unsigned long long* d_stats = nullptr;
+    unsigned long long* d_prof = nullptr;  // diagnostic builds only
     float* d_rgb = nullptr;  // staging for hpt_resolve
     // wavefront state
     uint64_t wf_capacity = 1ull << 22;
@@ -525,6 +553,10 @@ int hpt_context_create(int device, hpt_ctx** out) {
         delete ctx;
         return fail(HPT_ERR_HIP, "stats buffer: %s", hipGetErrorString(e));
     }
+#ifdef HPT_PROFILE
+    (void)hipMalloc((void**)&ctx->d_prof, 3 * kProfSections * sizeof(unsigned long long));
+    (void)hipMemset(ctx->d_prof, 0, 3 * kProfSections * sizeof(unsigned long long));
+#endif
     *out = ctx;
     return HPT_OK;
 }
@@ -638,6 +670,7 @@ int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* sc) {
     S.width = sc->width;
     S.height = sc->height;
     S.seed = seed;
+    S.prof = ctx->d_prof;
     const uint64_t f4 = 2ull * nn + 4ull * nt;
     S.lds_float4s = (f4 * 16ull <= kLdsLimit) ? (uint32_t)f4 : 0u;
     S.variant = !S.lds_float4s ? kSceneGlobal : (nt <= 32 ? kSceneTiny32 : (nt <= 64 ? kSceneTiny64 : kSceneLds));
@@ -701,7 +734,10 @@ int hpt_render(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sample
     if (mode == HPT_MODE_SINGLE_KERNEL) {
         const uint32_t waves_per_block = ((uint32_t)block + 63u) >> 6;
         const uint32_t blocks = (tiles + waves_per_block - 1u) / waves_per_block;
-        const uint32_t lds_mega = lds + waves_per_block * 192u * 8u;  // + per-wave tile accumulators
+        uint32_t lds_mega = lds + waves_per_block * 192u * 8u;  // + per-wave tile accumulators
+#ifdef HPT_PROFILE
+        lds_mega += waves_per_block * 3u * kProfSections * 8u;
+#endif
         for (uint32_t s = sample_begin; s < sample_begin + sample_count;) {
             const uint32_t n = (sample_begin + sample_count - s > ctx->spp_per_launch) ? ctx->spp_per_launch : sample_begin + sample_count - s;
             HPT_DISPATCH_SCENE(S.variant, {
@@ -839,6 +875,16 @@ int hpt_stats_get(hpt_ctx* ctx, hpt_stats* out) {
     out->paths = h[kStatPaths];
     out->kernel_ms = ctx->kernel_ms;
     out->launches = ctx->launches;
+#ifdef HPT_PROFILE
+    if (ctx->d_prof) {
+        unsigned long long pr[3 * kProfSections];
+        HIP_TRY(hipMemcpy(pr, ctx->d_prof, sizeof pr, hipMemcpyDeviceToHost));
+        const char* names[kProfSections] = {"regen", "box_closest", "tri_closest(+box)", "shadeA", "box_shadow", "tri_shadow(+box)", "shadeB", "wave_total"};
+        for (int i = 0; i < kProfSections; ++i)
+            fprintf(stderr, "PROF %-18s cycles %14llu  iters %12llu  avg_lanes %6.2f\n", names[i], pr[i], pr[kProfSections + i],
+                    pr[kProfSections + i] ? (double)pr[2 * kProfSections + i] / (double)pr[kProfSections + i] : 0.0);
+    }
+#endif
     return HPT_OK;
 }
 

@@ -19,6 +19,33 @@
 
 namespace hpt {
 
+// Diagnostic build only (-DHPT_PROFILE): per-section shader-clock and lane-occupancy
+// totals, written to a buffer of their own; the product build compiles none of it.
+#ifdef HPT_PROFILE
+enum { kProfRegen, kProfBoxC, kProfTriC, kProfShadeA, kProfBoxS, kProfTriS, kProfShadeB, kProfDone, kProfSections };
+struct ProfAcc {
+    unsigned long long* w;  // per-wave LDS: cyc[kProfSections], iters[kProfSections], lanes[kProfSections]
+};
+__device__ __forceinline__ bool prof_first_lane(unsigned long long exec) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(exec >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)exec, 0u)) == 0u;
+}
+__device__ __forceinline__ void prof_add(const ProfAcc& p, int idx, unsigned long long v) {
+    const unsigned long long exec = __ballot(true);
+    if (prof_first_lane(exec)) atomicAdd(p.w + idx, v);
+}
+#define PROF_ARG , ProfAcc& prof
+#define PROF_PASS , prof
+#define PROF_T0() const unsigned long long prof_t0 = __builtin_readcyclecounter()
+#define PROF_T1(id) prof_add(prof, id, __builtin_readcyclecounter() - prof_t0)
+#define PROF_ITER(id) do { prof_add(prof, kProfSections + (id), 1ull); prof_add(prof, 2 * kProfSections + (id), (unsigned long long)__popcll(__ballot(true))); } while (0)
+#else
+#define PROF_ARG
+#define PROF_PASS
+#define PROF_T0()
+#define PROF_T1(id)
+#define PROF_ITER(id)
+#endif
+
 // ---------------------------------------------------------------- vec3 ------
 // glm::vec3 semantics (external/glm/detail/func_geometric.inl:54-96):
 // dot = (x*x' + y*y') + z*z', cross as written there, normalize = v * (1/sqrt(dot)).
@@ -189,6 +216,7 @@ struct DevScene {
     uint32_t seed;
     uint32_t lds_float4s;  // > 0: nodes+tris are staged into LDS (2*num_nodes + 4*num_tris float4)
     int32_t variant;       // kSceneGlobal .. kSceneTiny64
+    unsigned long long* prof;  // diagnostic builds only (3 x kProfSections totals), else null
 };
 
 // Stage the node and triangle records into LDS (tiny scenes: the Cornell box is
@@ -279,7 +307,7 @@ HD bool tri_hit(const float4* __restrict__ T, int tri, f3 o, f3 d, double& t_out
 // are tested is decided by the box tests alone, so deferring the tests changes
 // no result; an occluded shadow ray merely finishes its box walk first.
 template <int kScene, bool kShadow>
-HD void trace(const DevScene& S, const float4* __restrict__ lds, f3 o, f3 d, double tmax, int& hit_tri, double& hit_t) {
+HD void trace(const DevScene& S, const float4* __restrict__ lds, f3 o, f3 d, double tmax, int& hit_tri, double& hit_t PROF_ARG) {
     const float4* N;
     const float4* T;
     if constexpr (kScene != kSceneGlobal) {
@@ -300,8 +328,10 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, f3 o, f3 d, dou
         using mask_t = typename std::conditional<kScene == kSceneTiny32, uint32_t, unsigned long long>::type;
         mask_t pending = 0;
         const float kInf = __builtin_inff();
+        PROF_T0();
         if (fabsf(inv.x) < kInf && fabsf(inv.y) < kInf && fabsf(inv.z) < kInf) {
             while (node < end) {
+                PROF_ITER(kShadow ? kProfBoxS : kProfBoxC);
                 const float4 lo = N[2 * node], hi = N[2 * node + 1];
                 const bool hit = box_hit_finite(lo, hi, o, inv);
                 if constexpr (kScene == kSceneTiny32) {
@@ -325,6 +355,7 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, f3 o, f3 d, dou
                 node = hit ? node + 1 : __float_as_int(lo.w);
             }
         }
+        PROF_T1(kShadow ? kProfBoxS : kProfBoxC);
         // cheap filter first: drop back-facing triangles (Triangle.hpp:168-169), so
         // that the expensive rounds below are only as many as the busiest lane needs
         for (mask_t m = pending; m;) {
@@ -333,6 +364,7 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, f3 o, f3 d, dou
             if (dot(d, xyz(T[4 * tri + 3])) > 0) pending &= ~((mask_t)1 << tri);
         }
         while (pending) {
+            PROF_ITER(kShadow ? kProfTriS : kProfTriC);
             const int tri = (kScene == kSceneTiny32) ? __ffs((int)pending) - 1 : __ffsll((long long)pending) - 1;
             pending &= pending - 1;
             double t;
@@ -351,6 +383,7 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, f3 o, f3 d, dou
                 }
             }
         }
+        PROF_T1(kShadow ? kProfTriS : kProfTriC);  // filter + tests (includes the box time, subtracted by the reader)
     } else {
         while (node < end) {
             const float4 lo = N[2 * node], hi = N[2 * node + 1];
@@ -500,8 +533,12 @@ HD void generate_camera_path(const DevScene& S, uint32_t pixel, uint32_t sample,
 // the caller ends it after max_depth bounces otherwise.  Counts shadow queries.
 template <int kScene>
 HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, Path& p, int hit_tri, double hit_t,
-                     uint32_t& shadow_queries) {
+                     uint32_t& shadow_queries PROF_ARG) {
     bool alive = true;
+#ifdef HPT_PROFILE
+    unsigned long long prof_s0 = __builtin_readcyclecounter();
+    PROF_ITER(kProfShadeA);
+#endif
     do {
         if (hit_tri < 0) {
             alive = false;
@@ -569,7 +606,14 @@ HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, Path& p,
                 int occ_tri;
                 double occ_t;
                 ++shadow_queries;
-                trace<kScene, true>(S, lds, so, wi, (double)length(px), occ_tri, occ_t);
+#ifdef HPT_PROFILE
+                prof_add(prof, kProfShadeA, __builtin_readcyclecounter() - prof_s0);
+#endif
+                trace<kScene, true>(S, lds, so, wi, (double)length(px), occ_tri, occ_t PROF_PASS);
+#ifdef HPT_PROFILE
+                prof_s0 = __builtin_readcyclecounter();
+                PROF_ITER(kProfShadeB);
+#endif
                 if (occ_tri < 0) {
                     f3 bsdf;
                     float bsdfPdf;
@@ -599,6 +643,9 @@ HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, Path& p,
         p.d = wi;
     } while (false);
 
+#ifdef HPT_PROFILE
+    prof_add(prof, kProfShadeB, __builtin_readcyclecounter() - prof_s0);
+#endif
     p.depth++;  // :268-271
     if (isnan(p.rad.x) || isnan(p.rad.y) || isnan(p.rad.z) || isinf(p.rad.x) || isinf(p.rad.y) || isinf(p.rad.z))
         p.rad = mk(0.0f);
