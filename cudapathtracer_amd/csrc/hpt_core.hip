@@ -71,7 +71,7 @@ __global__ void k_intersect_batch(DevScene S, size_t n, const float* __restrict_
                                   const uint8_t* __restrict__ shadow, const double* __restrict__ tmax,
                                   int32_t* __restrict__ prim, double* __restrict__ t_out) {
     extern __shared__ float4 lds[];
-    if constexpr (kScene != kSceneGlobal) stage_scene_lds<kScene == kSceneTiny32>(S, lds);
+    if constexpr (kScene != kSceneGlobal) stage_scene_lds<kScene == kSceneTiny32 || kScene == kSceneSweep>(S, lds);
     const size_t stride = (size_t)gridDim.x * blockDim.x;
 #ifdef HPT_PROFILE
     __shared__ unsigned long long prof_dummy[3 * kProfSections];
@@ -97,8 +97,10 @@ __device__ __forceinline__ void accumulate_pixel(int64_t* accum, uint32_t pixel,
     atomicAdd(a + 2, (unsigned long long)radiance_to_fixed(rad.z));
 }
 
+// waves per SIMD the single-kernel variant is compiled for: 5 (96 VGPRs, ~30 spilled dwords)
+// measured 6 % faster than 4 (no spills) and 2 % faster than 6 on the Cornell workload
 #ifndef HPT_MEGA_WAVES
-#define HPT_MEGA_WAVES 1
+#define HPT_MEGA_WAVES 5
 #endif
 // Mode 1.  One wave owns one 8x8 pixel tile and traces `s_count` samples of each
 // of its pixels.  The tile's (pixel, sample) work items form a pool that the
@@ -117,7 +119,7 @@ k_render_mega(DevScene S, int max_depth, uint32_t s_begin, uint32_t s_count, int
     const uint32_t wave_lanes = min(64u, blockDim.x - wave * 64u);  // the last wave of an odd-sized block is partial
     unsigned long long* tile_acc = reinterpret_cast<unsigned long long*>(lds + S.lds_float4s) + wave * 192u;
     for (uint32_t i = lane; i < 192u; i += wave_lanes) tile_acc[i] = 0ull;
-    if constexpr (kScene != kSceneGlobal) stage_scene_lds<kScene == kSceneTiny32>(S, lds);
+    if constexpr (kScene != kSceneGlobal) stage_scene_lds<kScene == kSceneTiny32 || kScene == kSceneSweep>(S, lds);
 
     const uint32_t W = (uint32_t)S.width, H = (uint32_t)S.height;
     const uint32_t tiles_x = (W + 7u) >> 3, tiles_y = (H + 7u) >> 3;
@@ -144,8 +146,19 @@ k_render_mega(DevScene S, int max_depth, uint32_t s_begin, uint32_t s_count, int
                 const uint32_t k = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
                 next += (uint32_t)__popcll(need);
                 if (!alive && k < total) {
-                    slot = k % nv;
-                    generate_camera_path(S, (y0 + slot / vw) * W + x0 + slot % vw, s_begin + k / nv, p);
+                    uint32_t px, py, smp;
+                    if (nv == 64u) {  // full tile (wave-uniform): no integer divisions
+                        slot = k & 63u;
+                        smp = k >> 6;
+                        px = slot & 7u;
+                        py = slot >> 3;
+                    } else {
+                        slot = k % nv;
+                        smp = k / nv;
+                        px = slot % vw;
+                        py = slot / vw;
+                    }
+                    generate_camera_path(S, (y0 + py) * W + x0 + px, s_begin + smp, p);
                     ++n_paths;
                     alive = true;
                 }
@@ -247,7 +260,7 @@ __global__ void __launch_bounds__(256)
 k_wf_extend(DevScene S, WfQueue q, const uint32_t* __restrict__ live_count, int2* __restrict__ hits,
             unsigned long long* __restrict__ stats) {
     extern __shared__ float4 lds[];
-    if constexpr (kScene != kSceneGlobal) stage_scene_lds<kScene == kSceneTiny32>(S, lds);
+    if constexpr (kScene != kSceneGlobal) stage_scene_lds<kScene == kSceneTiny32 || kScene == kSceneSweep>(S, lds);
     const uint32_t count = *live_count;
     const uint32_t stride = gridDim.x * blockDim.x;
     uint32_t n_closest = 0;
@@ -279,7 +292,7 @@ k_wf_shade(DevScene S, int max_depth, WfQueue q_in, const int2* __restrict__ hit
            WfQueue q_out, uint32_t* __restrict__ live_out, int64_t* __restrict__ accum,
            unsigned long long* __restrict__ stats) {
     extern __shared__ float4 lds[];
-    if constexpr (kScene != kSceneGlobal) stage_scene_lds<kScene == kSceneTiny32>(S, lds);
+    if constexpr (kScene != kSceneGlobal) stage_scene_lds<kScene == kSceneTiny32 || kScene == kSceneSweep>(S, lds);
     const uint32_t count = *live_in;
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t lane = threadIdx.x & 63u;
@@ -332,7 +345,8 @@ __global__ void k_resolve(const int64_t* __restrict__ accum, size_t n, double de
     case kSceneGlobal: { constexpr int kS = kSceneGlobal; CALL; } break;          \
     case kSceneLds: { constexpr int kS = kSceneLds; CALL; } break;                \
     case kSceneTiny32: { constexpr int kS = kSceneTiny32; CALL; } break;          \
-    default: { constexpr int kS = kSceneTiny64; CALL; } break;                    \
+    case kSceneTiny64: { constexpr int kS = kSceneTiny64; CALL; } break;          \
+    default: { constexpr int kS = kSceneSweep; CALL; } break;                     \
     }
 
 // ------------------------------------------------------------------ context --
@@ -673,12 +687,16 @@ int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* sc) {
     S.prof = ctx->d_prof;
     const uint64_t f4 = 2ull * nn + 4ull * nt;
     S.lds_float4s = (f4 * 16ull <= kLdsLimit) ? (uint32_t)f4 : 0u;
+    // (the wave-uniform sweep, kSceneSweep, measured slower than the per-lane walk: 17.1 vs 19.1 Grays/s on
+    // incoherent rays; it stays selectable with HPT_TRACE_VARIANT=4 for experiments)
     S.variant = !S.lds_float4s ? kSceneGlobal : (nt <= 32 ? kSceneTiny32 : (nt <= 64 ? kSceneTiny64 : kSceneLds));
     if (const char* e = getenv("HPT_TRACE_VARIANT")) {  // experiments: force a simpler variant
         const int v = atoi(e);
         if (v == kSceneGlobal) { S.variant = kSceneGlobal; S.lds_float4s = 0; }
         else if (v == kSceneLds && S.lds_float4s) S.variant = kSceneLds;
         else if (v == kSceneTiny64 && S.lds_float4s && nt <= 64) S.variant = kSceneTiny64;
+        else if (v == kSceneTiny32 && S.lds_float4s && nt <= 32) S.variant = kSceneTiny32;
+        else if (v == kSceneSweep && S.lds_float4s && nt <= 32 && nn <= kSweepMaxNodes) S.variant = kSceneSweep;
     }
     ctx->has_scene = true;
     return HPT_OK;

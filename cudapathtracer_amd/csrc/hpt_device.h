@@ -88,8 +88,9 @@ struct u4 {
 HD u4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int round = 0; round < 10; ++round) {
-        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        // one 32x32->64 multiply per product (the 32-bit integer multiplies are the slow VALU ops)
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         uint32_t n0 = hi1 ^ c1 ^ k0;
         uint32_t n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
@@ -242,10 +243,16 @@ enum {
     kSceneGlobal = 0,  // records read through L1/L2; triangle tested when its leaf is reached
     kSceneLds = 1,     // records staged in LDS; same loop
     kSceneTiny32 = 2,  // LDS, <= 32 triangles: the box walk only *marks* the triangles of the
-    kSceneTiny64 = 3   // leaves it reaches (one bit each, 32- or 64-bit mask per lane); the
+    kSceneTiny64 = 3,  // leaves it reaches (one bit each, 32- or 64-bit mask per lane); the
                        // triangle tests run afterwards in a loop of their own, so lanes that
                        // are at interior nodes never idle through another lane's triangle test
+    kSceneSweep = 4    // <= 32 triangles and <= kSweepMaxNodes nodes: as Tiny32, but the box phase
+                       // is a wave-uniform sweep over ALL nodes in pre-order: the node record is
+                       // fetched once per wave with scalar loads (operands in SGPRs, no LDS access,
+                       // no dependent address), each lane takes part at a node only if its own
+                       // walk would be there.  Same tests per lane, no load latency on the walk.
 };
+constexpr uint32_t kSweepMaxNodes = 96;
 
 // Bounds3::IntersectP (common/Bounds3.hpp:93-118): float slab test, no t-range
 // culling, every comparison false on NaN.
@@ -324,17 +331,43 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, f3 o, f3 d, dou
     double best_t = (double)kInfinity;
     int node = 0;
     const int end = (int)S.num_nodes;
-    if constexpr (kScene == kSceneTiny32 || kScene == kSceneTiny64) {
-        using mask_t = typename std::conditional<kScene == kSceneTiny32, uint32_t, unsigned long long>::type;
+    if constexpr (kScene == kSceneTiny32 || kScene == kSceneTiny64 || kScene == kSceneSweep) {
+        constexpr bool kMask32 = (kScene != kSceneTiny64);
+        using mask_t = typename std::conditional<kMask32, uint32_t, unsigned long long>::type;
         mask_t pending = 0;
         const float kInf = __builtin_inff();
         PROF_T0();
-        if (fabsf(inv.x) < kInf && fabsf(inv.y) < kInf && fabsf(inv.z) < kInf) {
+        const bool finite = fabsf(inv.x) < kInf && fabsf(inv.y) < kInf && fabsf(inv.z) < kInf;
+        if constexpr (kScene == kSceneSweep) {
+            int cur = finite ? 0 : end;  // lanes with a zero direction component take the exact walk below
+            // constant address space: the table is immutable while kernels run, and a
+            // wave-uniform index then compiles to scalar loads (node operands in SGPRs)
+            typedef float raw_f4 __attribute__((ext_vector_type(4)));
+            typedef __attribute__((address_space(4))) const raw_f4 const_f4;
+            const const_f4* G = (const const_f4*)(uintptr_t)S.nodes;
+#pragma unroll 4
+            for (int n = 0; n < end; ++n) {
+                PROF_ITER(kShadow ? kProfBoxS : kProfBoxC);
+                const raw_f4 rlo = G[2 * n], rhi = G[2 * n + 1];  // wave-uniform address
+                const float4 lo = make_float4(rlo.x, rlo.y, rlo.z, rlo.w), hi = make_float4(rhi.x, rhi.y, rhi.z, rhi.w);
+                const int tri = __float_as_int(hi.w);
+                const uint32_t bit = tri >= 0 ? 1u << tri : 0u;
+                const int miss = __float_as_int(lo.w);
+                // no per-lane branch: every lane evaluates the test, only lanes whose own
+                // walk is at this node use the result
+                const bool at = cur == n;
+                const bool hit = box_hit_finite(lo, hi, o, inv);
+                pending |= (at && hit) ? bit : 0u;
+                cur = at ? (hit ? n + 1 : miss) : cur;
+            }
+            node = finite ? end : 0;
+        }
+        if (finite) {
             while (node < end) {
                 PROF_ITER(kShadow ? kProfBoxS : kProfBoxC);
                 const float4 lo = N[2 * node], hi = N[2 * node + 1];
                 const bool hit = box_hit_finite(lo, hi, o, inv);
-                if constexpr (kScene == kSceneTiny32) {
+                if constexpr (kMask32) {
                     pending |= hit ? __float_as_uint(hi.w) : 0u;  // staged as a leaf bit
                 } else {
                     const int tri = __float_as_int(hi.w);
@@ -346,7 +379,7 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, f3 o, f3 d, dou
             while (node < end) {
                 const float4 lo = N[2 * node], hi = N[2 * node + 1];
                 const bool hit = box_hit(lo, hi, o, inv, nx, ny, nz);
-                if constexpr (kScene == kSceneTiny32) {
+                if constexpr (kMask32) {
                     pending |= hit ? __float_as_uint(hi.w) : 0u;
                 } else {
                     const int tri = __float_as_int(hi.w);
@@ -359,13 +392,13 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, f3 o, f3 d, dou
         // cheap filter first: drop back-facing triangles (Triangle.hpp:168-169), so
         // that the expensive rounds below are only as many as the busiest lane needs
         for (mask_t m = pending; m;) {
-            const int tri = (kScene == kSceneTiny32) ? __ffs((int)m) - 1 : __ffsll((long long)m) - 1;
+            const int tri = kMask32 ? __ffs((int)m) - 1 : __ffsll((long long)m) - 1;
             m &= m - 1;
             if (dot(d, xyz(T[4 * tri + 3])) > 0) pending &= ~((mask_t)1 << tri);
         }
         while (pending) {
             PROF_ITER(kShadow ? kProfTriS : kProfTriC);
-            const int tri = (kScene == kSceneTiny32) ? __ffs((int)pending) - 1 : __ffsll((long long)pending) - 1;
+            const int tri = kMask32 ? __ffs((int)pending) - 1 : __ffsll((long long)pending) - 1;
             pending &= pending - 1;
             double t;
             if (tri_hit(T, tri, o, d, t)) {
@@ -603,6 +636,10 @@ HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, Path& p,
                 const f3 px = lx - coords;
                 const f3 wi = normalize(px);
                 const f3 so = coords + wi * kEpsilon5;
+                // everything that depends on the light sample is reduced to scalars here, so
+                // that only they stay live across the shadow traversal
+                const float cos_theta_prime = satDot(ln, -wi);
+                const float r2 = dot(lx - coords, lx - coords);
                 int occ_tri;
                 double occ_t;
                 ++shadow_queries;
@@ -619,8 +656,6 @@ HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, Path& p,
                     float bsdfPdf;
                     mat_eval(material, wi, wo, normal, bsdf, bsdfPdf);
                     const float cos_theta = satDot(normal, wi);
-                    const float cos_theta_prime = satDot(ln, -wi);
-                    const float r2 = dot(lx - coords, lx - coords);
                     const float weight = powerHeuristic(lightPdf, bsdfPdf);
                     p.rad = p.rad + p.thr * lemit * bsdf * cos_theta * cos_theta_prime / r2 / lightSamplePdf * weight;
                 }
