@@ -4,8 +4,8 @@
     python bench.py --gpus N --steps K --warmup W
 
 A *step* is one pass of the hot path over one batch: --spp-per-step samples of
-every pixel of the 1k x 1k image (default 16 -> 16.8 M camera paths, about
-195 M rays).  With N > 1 (one process per GPU, launched by torch.distributed.run)
+every pixel of the 1k x 1k image (default 64 -> 67 M camera paths, about
+780 M rays; the 4096-spp configuration is 64 such steps).  With N > 1 (one process per GPU, launched by torch.distributed.run)
 every rank traces its own, disjoint sample ranges (weak scaling: per-GPU work
 per step is fixed) and the int64 accumulation buffers are summed onto rank 0
 with ONE RCCL reduce at the end of the timed region, which also contains the
@@ -57,9 +57,9 @@ def cpu_baseline(width, height, depth, spp, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--spp-per-step", type=int, default=16)
+    ap.add_argument("--spp-per-step", type=int, default=64)
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--depth", type=int, default=20)
@@ -83,15 +83,37 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # HPT_BENCH_BACKEND=gloo + HPT_BENCH_DEVICE=0: rehearse the multi-rank flow on a one-GPU box
+    backend = os.environ.get("HPT_BENCH_BACKEND", "nccl")
+    dev_index = int(os.environ.get("HPT_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+
+    def reduce_sum(t):
+        if backend == "nccl":
+            dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+        else:  # rehearsal path only
+            h = t.cpu()
+            dist.reduce(h, dst=0, op=dist.ReduceOp.SUM)
+            t.copy_(h)
+
+    def all_reduce(t, op):
+        if backend == "nccl":
+            dist.all_reduce(t, op=op)
+        else:
+            h = t.cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
 
     W, H, depth, spp_step = args.width, args.height, args.depth, args.spp_per_step
     scene = hp.Scene.CreateBuiltinScene(hp.Scene.CornellBox, depth, W, H)
-    ctx = hp.Context(local_rank).upload(scene)
+    ctx = hp.Context(dev_index).upload(scene)
     accum = torch.zeros(3 * W * H, dtype=torch.int64, device=dev)
     rgb = torch.zeros(3 * W * H, dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream()
@@ -106,7 +128,7 @@ def main():
     total_spp = args.steps * world * spp_step
     warm_base = total_spp  # warm-up samples lie outside the timed range
     if world > 1:  # warm up the communicator as well
-        dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+        reduce_sum(accum)
     for k in range(args.warmup):
         ctx.render(args.mode, args.block, depth, warm_base + (k * world + rank) * spp_step, spp_step, accum=accum, stream=stream)
     barrier()
@@ -118,7 +140,7 @@ def main():
     for k in range(args.steps):
         ctx.render(args.mode, args.block, depth, (k * world + rank) * spp_step, spp_step, accum=accum, stream=stream)
     if world > 1:
-        dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+        reduce_sum(accum)
     if rank == 0:
         ctx.resolve_dev(total_spp, rgb, accum=accum, stream=stream)
     barrier()
@@ -129,8 +151,8 @@ def main():
     agg = torch.tensor([float(rays), float(st["paths"]), float(st["closest_queries"])], dtype=torch.float64, device=dev)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
-        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        all_reduce(agg, dist.ReduceOp.SUM)
+        all_reduce(tmax, dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
     total_rays, total_paths, total_closest = (float(v) for v in agg.tolist())
 
