@@ -18,6 +18,7 @@
 #include <cstring>
 #include <random>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include <omp.h>
@@ -1092,6 +1093,8 @@ int orc_bvh_dump(const orc_scene* s, int mesh, float* bounds6, int* payload, flo
     std::vector<Node*> nodes;
     preorder(bvh->root, nodes);
     if (!bounds6) return (int)nodes.size();
+    std::unordered_map<const Node*, int> rank_of;
+    for (size_t i = 0; i < nodes.size(); ++i) rank_of[nodes[i]] = (int)i;
     for (size_t i = 0; i < nodes.size(); ++i) {
         Node* n = nodes[i];
         bounds6[6 * i + 0] = n->bounds.pMin.x; bounds6[6 * i + 1] = n->bounds.pMin.y; bounds6[6 * i + 2] = n->bounds.pMin.z;
@@ -1101,11 +1104,7 @@ int orc_bvh_dump(const orc_scene* s, int mesh, float* bounds6, int* payload, flo
         else if (n->mesh >= 0) payload[i] = n->mesh;
         else payload[i] = (int)(n->triangle - s->sc.meshes[mesh]->triangles.data());
         area[i] = n->area;
-        int mr = (int)nodes.size();
-        if (n->nextIfMiss)
-            for (size_t k = 0; k < nodes.size(); ++k)
-                if (nodes[k] == n->nextIfMiss) mr = (int)k;
-        miss_rank[i] = mr;
+        miss_rank[i] = n->nextIfMiss ? rank_of.at(n->nextIfMiss) : (int)nodes.size();
     }
     return (int)nodes.size();
 }

@@ -20,6 +20,7 @@
 #include <cstring>
 #include <unistd.h>
 #include <fcntl.h>
+#include <unordered_map>
 #include <vector>
 
 namespace {
@@ -180,6 +181,8 @@ int ref_bvh_dump(int mesh, float* bounds6, int* payload, float* area, int* miss_
     std::vector<BVHBuildNode*> nodes;
     collect_preorder(bvh->root, nodes);
     if (!bounds6) return (int)nodes.size();
+    std::unordered_map<const BVHBuildNode*, int> rank_of;
+    for (size_t i = 0; i < nodes.size(); ++i) rank_of[nodes[i]] = (int)i;
     for (size_t i = 0; i < nodes.size(); ++i) {
         BVHBuildNode* n = nodes[i];
         bounds6[6 * i + 0] = n->bounds.pMin.x; bounds6[6 * i + 1] = n->bounds.pMin.y; bounds6[6 * i + 2] = n->bounds.pMin.z;
@@ -189,11 +192,7 @@ int ref_bvh_dump(int mesh, float* bounds6, int* payload, float* area, int* miss_
         else if (n->mesh) payload[i] = mesh_index_of(n->mesh);
         else payload[i] = (int)(n->triangle - g_scene->meshes_data[mesh]->triangles);
         area[i] = n->area;
-        int mr = (int)nodes.size();
-        if (n->nextIfMiss)
-            for (size_t k = 0; k < nodes.size(); ++k)
-                if (nodes[k] == n->nextIfMiss) mr = (int)k;
-        miss_rank[i] = mr;
+        miss_rank[i] = n->nextIfMiss ? rank_of.at(n->nextIfMiss) : (int)nodes.size();
         // nextIfHit must be the pre-order successor (BVH.cpp:53-62)
         BVHBuildNode* succ = i + 1 < nodes.size() ? nodes[i + 1] : nullptr;
         if (n->nextIfHit != succ) return -1;
