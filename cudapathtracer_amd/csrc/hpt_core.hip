@@ -73,6 +73,7 @@ __global__ void k_intersect_batch(DevScene S, size_t n, const float* __restrict_
     extern __shared__ float4 lds[];
     if constexpr (kScene != kSceneGlobal) stage_scene_lds<kScene == kSceneTiny32 || kScene == kSceneSweep>(S, lds);
     const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const TriQueue tq{reinterpret_cast<uint32_t*>(lds + S.lds_float4s) + threadIdx.x, blockDim.x};
 #ifdef HPT_PROFILE
     __shared__ unsigned long long prof_dummy[3 * kProfSections];
     ProfAcc prof;
@@ -83,8 +84,8 @@ __global__ void k_intersect_batch(DevScene S, size_t n, const float* __restrict_
         const f3 rd = mk(d[3 * r], d[3 * r + 1], d[3 * r + 2]);
         int tri;
         double t;
-        if (shadow && shadow[r]) trace<kScene, true>(S, lds, ro, rd, tmax[r], tri, t PROF_PASS);
-        else trace<kScene, false>(S, lds, ro, rd, 0.0, tri, t PROF_PASS);
+        if (shadow && shadow[r]) trace<kScene, true>(S, lds, tq, ro, rd, tmax[r], tri, t PROF_PASS);
+        else trace<kScene, false>(S, lds, tq, ro, rd, 0.0, tri, t PROF_PASS);
         prim[r] = tri < 0 ? -1 : __float_as_int(S.tris[4 * tri + 2].w);
         t_out[r] = t;
     }
@@ -119,6 +120,8 @@ k_render_mega(DevScene S, int max_depth, uint32_t s_begin, uint32_t s_count, int
     const uint32_t wave_lanes = min(64u, blockDim.x - wave * 64u);  // the last wave of an odd-sized block is partial
     unsigned long long* tile_acc = reinterpret_cast<unsigned long long*>(lds + S.lds_float4s) + wave * 192u;
     for (uint32_t i = lane; i < 192u; i += wave_lanes) tile_acc[i] = 0ull;
+    // triangle queues (variants without a pending mask) lie behind all waves' accumulators
+    const TriQueue tq{reinterpret_cast<uint32_t*>(lds + S.lds_float4s) + waves_per_block * 384u + threadIdx.x, blockDim.x};
     if constexpr (kScene != kSceneGlobal) stage_scene_lds<kScene == kSceneTiny32 || kScene == kSceneSweep>(S, lds);
 
     const uint32_t W = (uint32_t)S.width, H = (uint32_t)S.height;
@@ -135,7 +138,7 @@ k_render_mega(DevScene S, int max_depth, uint32_t s_begin, uint32_t s_count, int
         Path p;
 #ifdef HPT_PROFILE
         ProfAcc prof;
-        prof.w = tile_acc + 192u * (waves_per_block - wave) + wave * 3u * kProfSections;  // behind all waves' accumulators
+        prof.w = tile_acc + 192u * (waves_per_block - wave) + (kTriQueue * blockDim.x + 1u) / 2u + wave * 3u * kProfSections;  // behind accumulators and queues
         for (uint32_t i = lane; i < 3u * kProfSections; i += wave_lanes) prof.w[i] = 0ull;
         const unsigned long long prof_start = __builtin_readcyclecounter();
 #endif
@@ -168,8 +171,8 @@ k_render_mega(DevScene S, int max_depth, uint32_t s_begin, uint32_t s_count, int
                 int tri;
                 double t;
                 ++n_closest;
-                trace<kScene, false>(S, lds, p.o, p.d, 0.0, tri, t PROF_PASS);
-                alive = shade_bounce<kScene>(S, lds, p, tri, t, n_shadow PROF_PASS) && p.depth < max_depth;
+                trace<kScene, false>(S, lds, tq, p.o, p.d, 0.0, tri, t PROF_PASS);
+                alive = shade_bounce<kScene>(S, lds, tq, p, tri, t, n_shadow PROF_PASS) && p.depth < max_depth;
                 if (!alive) {
                     atomicAdd(tile_acc + 3u * slot + 0u, (unsigned long long)radiance_to_fixed(p.rad.x));
                     atomicAdd(tile_acc + 3u * slot + 1u, (unsigned long long)radiance_to_fixed(p.rad.y));
@@ -263,6 +266,7 @@ k_wf_extend(DevScene S, WfQueue q, const uint32_t* __restrict__ live_count, int2
     if constexpr (kScene != kSceneGlobal) stage_scene_lds<kScene == kSceneTiny32 || kScene == kSceneSweep>(S, lds);
     const uint32_t count = *live_count;
     const uint32_t stride = gridDim.x * blockDim.x;
+    const TriQueue tq{reinterpret_cast<uint32_t*>(lds + S.lds_float4s) + threadIdx.x, blockDim.x};
     uint32_t n_closest = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
         const float4 a = q.a[i], b = q.b[i];
@@ -275,7 +279,7 @@ k_wf_extend(DevScene S, WfQueue q, const uint32_t* __restrict__ live_count, int2
             ProfAcc prof;
             prof.w = prof_dummy;
 #endif
-            trace<kScene, false>(S, lds, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), 0.0, tri, t PROF_PASS);
+            trace<kScene, false>(S, lds, tq, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), 0.0, tri, t PROF_PASS);
         }
         hits[i] = make_int2(tri, __float_as_int((float)t));
     }
@@ -296,6 +300,7 @@ k_wf_shade(DevScene S, int max_depth, WfQueue q_in, const int2* __restrict__ hit
     const uint32_t count = *live_in;
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t lane = threadIdx.x & 63u;
+    const TriQueue tq{reinterpret_cast<uint32_t*>(lds + S.lds_float4s) + threadIdx.x, blockDim.x};
     uint32_t n_shadow = 0;
     // all lanes of a wave run the same number of iterations so that the
     // ballot below always sees the whole wave
@@ -315,7 +320,7 @@ k_wf_shade(DevScene S, int max_depth, WfQueue q_in, const int2* __restrict__ hit
                 ProfAcc prof;
                 prof.w = prof_dummy;
 #endif
-                keep = shade_bounce<kScene>(S, lds, p, h.x, (double)__int_as_float(h.y), n_shadow PROF_PASS) && p.depth < max_depth;
+                keep = shade_bounce<kScene>(S, lds, tq, p, h.x, (double)__int_as_float(h.y), n_shadow PROF_PASS) && p.depth < max_depth;
                 if (!keep) accumulate_pixel(accum, p.pixel, p.rad);
             }
         }
@@ -519,7 +524,11 @@ int settle_events(hpt_ctx* ctx) {
     return HPT_OK;
 }
 
-uint32_t lds_bytes(const DevScene& S) { return S.lds_float4s * 16u; }
+// dynamic LDS of the traversal kernels: the staged scene (if any) + the per-lane
+// triangle queues of the variants that use them
+uint32_t lds_bytes(const DevScene& S, int block) {
+    return S.lds_float4s * 16u + (S.variant <= kSceneLds ? (uint32_t)block * kTriQueue * 4u : 0u);
+}
 
 int grid_for(const hpt_ctx* ctx, uint64_t work, int block) {
     // grid-stride kernels: twice the workgroups that are resident at full
@@ -743,7 +752,7 @@ int hpt_render(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sample
     const DevScene& S = ctx->S;
     const uint32_t tiles = (((uint32_t)S.width + 7u) >> 3) * (((uint32_t)S.height + 7u) >> 3);
     const uint64_t lanes = (uint64_t)tiles * 64ull;  // lanes per sample (edge tiles are partly idle)
-    const uint32_t lds = lds_bytes(S);
+    const uint32_t lds = lds_bytes(S, 0);  // scene only; queues are added per launch below
 
     hipEvent_t ev0 = take_event(ctx), ev1 = take_event(ctx);
     HIP_TRY(hipEventRecord(ev0, stream));
@@ -752,7 +761,7 @@ int hpt_render(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sample
     if (mode == HPT_MODE_SINGLE_KERNEL) {
         const uint32_t waves_per_block = ((uint32_t)block + 63u) >> 6;
         const uint32_t blocks = (tiles + waves_per_block - 1u) / waves_per_block;
-        uint32_t lds_mega = lds + waves_per_block * 192u * 8u;  // + per-wave tile accumulators
+        uint32_t lds_mega = lds + waves_per_block * 192u * 8u + (lds_bytes(S, block) - lds);  // + per-wave tile accumulators + queues
 #ifdef HPT_PROFILE
         lds_mega += waves_per_block * 3u * kProfSections * 8u;
 #endif
@@ -784,8 +793,8 @@ int hpt_render(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sample
                 const WfQueue& qi = q[it & 1];
                 const WfQueue& qo = q[(it + 1) & 1];
                 HPT_DISPATCH_SCENE(S.variant, {
-                    hipLaunchKernelGGL((k_wf_extend<kS>), dim3(grid), dim3(wblock), lds, stream, S, qi, ctx->d_live + it, ctx->d_hits, ctx->d_stats);
-                    hipLaunchKernelGGL((k_wf_shade<kS>), dim3(grid), dim3(wblock), lds, stream, S, max_depth, qi, ctx->d_hits, ctx->d_live + it, qo, ctx->d_live + it + 1, accum, ctx->d_stats);
+                    hipLaunchKernelGGL((k_wf_extend<kS>), dim3(grid), dim3(wblock), lds_bytes(S, wblock), stream, S, qi, ctx->d_live + it, ctx->d_hits, ctx->d_stats);
+                    hipLaunchKernelGGL((k_wf_shade<kS>), dim3(grid), dim3(wblock), lds_bytes(S, wblock), stream, S, max_depth, qi, ctx->d_hits, ctx->d_live + it, qo, ctx->d_live + it + 1, accum, ctx->d_stats);
                 })
                 HIP_TRY(hipGetLastError());
                 launches += 2;
@@ -828,7 +837,7 @@ int hpt_intersect_batch_dev(hpt_ctx* ctx, size_t n, const float* o_dev, const fl
     if (block < 1 || block > 1024) return fail(HPT_ERR_INVALID_ARGUMENT, "block size %d not in [1, 1024]", block);
     if (int rc = set_device(ctx)) return rc;
     const DevScene& S = ctx->S;
-    const uint32_t lds = lds_bytes(S);
+    const uint32_t lds = lds_bytes(S, block);
     const int grid = grid_for(ctx, n, block);
     HPT_DISPATCH_SCENE(S.variant, {
         hipLaunchKernelGGL((k_intersect_batch<kS>), dim3(grid), dim3(block), lds, (hipStream_t)stream, S, n, o_dev, d_dev, shadow_dev, tmax_dev, prim_dev, t_dev);

@@ -313,8 +313,16 @@ HD bool tri_hit(const float4* __restrict__ T, int tri, f3 o, f3 d, double& t_out
 // kShadow: any-hit with t < tmax - Epsilon4 (BVH.hpp:121-127).  Which triangles
 // are tested is decided by the box tests alone, so deferring the tests changes
 // no result; an occluded shadow ray merely finishes its box walk first.
+// Per-lane queue of leaf triangles whose test is still to be run (variants
+// kSceneGlobal / kSceneLds): kTriQueue entries in LDS, entry k of a lane at q[k * stride].
+constexpr uint32_t kTriQueue = 8;
+struct TriQueue {
+    uint32_t* q;
+    uint32_t stride;
+};
+
 template <int kScene, bool kShadow>
-HD void trace(const DevScene& S, const float4* __restrict__ lds, f3 o, f3 d, double tmax, int& hit_tri, double& hit_t PROF_ARG) {
+HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3 o, f3 d, double tmax, int& hit_tri, double& hit_t PROF_ARG) {
     const float4* N;
     const float4* T;
     if constexpr (kScene != kSceneGlobal) {
@@ -418,19 +426,35 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, f3 o, f3 d, dou
         }
         PROF_T1(kShadow ? kProfTriS : kProfTriC);  // filter + tests (includes the box time, subtracted by the reader)
     } else {
-        while (node < end) {
-            const float4 lo = N[2 * node], hi = N[2 * node + 1];
-            int next = __float_as_int(lo.w);
-            if (box_hit(lo, hi, o, inv, nx, ny, nz)) {
-                next = node + 1;
+        // Larger scenes: the box walk queues the triangles of the leaves it reaches
+        // (up to kTriQueue per lane) and the tests run in a loop of their own, in
+        // queue order = visit order, so the strict `<` update sees the reference's
+        // sequence.  A lane whose queue is full waits for the flush.
+        const float kInf = __builtin_inff();
+        const bool finite = fabsf(inv.x) < kInf && fabsf(inv.y) < kInf && fabsf(inv.z) < kInf;
+        uint32_t cnt = 0;
+        for (;;) {
+            while (node < end && cnt < kTriQueue) {
+                const float4 lo = N[2 * node], hi = N[2 * node + 1];
+                const bool hit = finite ? box_hit_finite(lo, hi, o, inv) : box_hit(lo, hi, o, inv, nx, ny, nz);
                 const int tri = __float_as_int(hi.w);
+                if (hit && tri >= 0) {
+                    tq.q[cnt * tq.stride] = (uint32_t)tri;
+                    ++cnt;
+                }
+                node = hit ? node + 1 : __float_as_int(lo.w);
+            }
+            if (cnt == 0) break;
+            for (uint32_t k = 0; k < cnt; ++k) {
+                const int tri = (int)tq.q[k * tq.stride];
                 double t;
-                if (tri >= 0 && tri_hit(T, tri, o, d, t)) {
+                if (tri_hit(T, tri, o, d, t)) {
                     if constexpr (kShadow) {
                         if (t < limit) {
                             best = tri;
                             best_t = t;
-                            next = end;
+                            node = end;
+                            break;
                         }
                     } else {
                         if (t < best_t) {
@@ -440,7 +464,8 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, f3 o, f3 d, dou
                     }
                 }
             }
-            node = next;
+            cnt = 0;
+            if (node >= end) break;
         }
     }
     hit_tri = best;
@@ -565,7 +590,7 @@ HD void generate_camera_path(const DevScene& S, uint32_t pixel, uint32_t sample,
 // this bounce for the reason "missed the scene" (remainingBounces = 0, :156-161);
 // the caller ends it after max_depth bounces otherwise.  Counts shadow queries.
 template <int kScene>
-HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, Path& p, int hit_tri, double hit_t,
+HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, Path& p, int hit_tri, double hit_t,
                      uint32_t& shadow_queries PROF_ARG) {
     bool alive = true;
 #ifdef HPT_PROFILE
@@ -646,7 +671,7 @@ HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, Path& p,
 #ifdef HPT_PROFILE
                 prof_add(prof, kProfShadeA, __builtin_readcyclecounter() - prof_s0);
 #endif
-                trace<kScene, true>(S, lds, so, wi, (double)length(px), occ_tri, occ_t PROF_PASS);
+                trace<kScene, true>(S, lds, tq, so, wi, (double)length(px), occ_tri, occ_t PROF_PASS);
 #ifdef HPT_PROFILE
                 prof_s0 = __builtin_readcyclecounter();
                 PROF_ITER(kProfShadeB);
