@@ -18,6 +18,7 @@
 // through L1/L2.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -98,10 +99,11 @@ __device__ __forceinline__ void accumulate_pixel(int64_t* accum, uint32_t pixel,
     atomicAdd(a + 2, (unsigned long long)radiance_to_fixed(rad.z));
 }
 
-// waves per SIMD the single-kernel variant is compiled for: 5 (96 VGPRs, ~30 spilled dwords)
-// measured 6 % faster than 4 (no spills) and 2 % faster than 6 on the Cornell workload
+// Waves per SIMD the single-kernel variant is compiled for.  4 = 116 VGPRs, no spills.
+// 5 (96 VGPRs, 19 dwords spilled to scratch) measured 4 % faster on the Cornell workload but
+// turns 75 MB of HBM writes per launch into 15 GB of scratch traffic; 6 and 8 are slower.
 #ifndef HPT_MEGA_WAVES
-#define HPT_MEGA_WAVES 5
+#define HPT_MEGA_WAVES 4
 #endif
 // Mode 1.  One wave owns one 8x8 pixel tile and traces `s_count` samples of each
 // of its pixels.  The tile's (pixel, sample) work items form a pool that the
@@ -127,7 +129,9 @@ k_render_mega(DevScene S, int max_depth, uint32_t s_begin, uint32_t s_count, int
     const uint32_t W = (uint32_t)S.width, H = (uint32_t)S.height;
     const uint32_t tiles_x = (W + 7u) >> 3, tiles_y = (H + 7u) >> 3;
     const uint32_t tile = blockIdx.x * waves_per_block + wave;  // wave-uniform
-    uint32_t n_closest = 0, n_shadow = 0, n_paths = 0;
+    // closest queries in the low, shadow queries in the high 16 bits: one register per lane
+    // (a lane runs at most spp_per_launch * max_depth <= 65535 bounces per launch, checked by the host)
+    uint32_t n_rays = 0, n_paths_wave = 0;
     if (tile < tiles_x * tiles_y) {
         const uint32_t x0 = (tile % tiles_x) * 8u, y0 = (tile / tiles_x) * 8u;
         const uint32_t vw = min(8u, W - x0), vh = min(8u, H - y0), nv = vw * vh;  // pixels of an edge tile
@@ -162,7 +166,6 @@ k_render_mega(DevScene S, int max_depth, uint32_t s_begin, uint32_t s_count, int
                         py = slot / vw;
                     }
                     generate_camera_path(S, (y0 + py) * W + x0 + px, s_begin + smp, p);
-                    ++n_paths;
                     alive = true;
                 }
             }
@@ -170,9 +173,9 @@ k_render_mega(DevScene S, int max_depth, uint32_t s_begin, uint32_t s_count, int
             if (alive) {
                 int tri;
                 double t;
-                ++n_closest;
+                ++n_rays;
                 trace<kScene, false>(S, lds, tq, p.o, p.d, 0.0, tri, t PROF_PASS);
-                alive = shade_bounce<kScene>(S, lds, tq, p, tri, t, n_shadow PROF_PASS) && p.depth < max_depth;
+                alive = shade_bounce<kScene, 0x10000u>(S, lds, tq, p, tri, t, n_rays PROF_PASS) && p.depth < max_depth;
                 if (!alive) {
                     atomicAdd(tile_acc + 3u * slot + 0u, (unsigned long long)radiance_to_fixed(p.rad.x));
                     atomicAdd(tile_acc + 3u * slot + 1u, (unsigned long long)radiance_to_fixed(p.rad.y));
@@ -185,6 +188,7 @@ k_render_mega(DevScene S, int max_depth, uint32_t s_begin, uint32_t s_count, int
         if (lane == 0 && S.prof)
             for (int i = 0; i < 3 * kProfSections; ++i) atomicAdd(S.prof + i, prof.w[i]);
 #endif
+        n_paths_wave = lane == 0 ? total : 0u;  // every item of the pool was traced
         unsigned long long* out = reinterpret_cast<unsigned long long*>(accum);
         for (uint32_t j = lane; j < nv; j += wave_lanes) {
             const unsigned long long pix = (unsigned long long)(y0 + j / vw) * W + x0 + j % vw;
@@ -193,9 +197,9 @@ k_render_mega(DevScene S, int max_depth, uint32_t s_begin, uint32_t s_count, int
             atomicAdd(out + 3ull * pix + 2ull, tile_acc[3u * j + 2u]);
         }
     }
-    atomicAdd(stats + kStatClosest, (unsigned long long)n_closest);
-    atomicAdd(stats + kStatShadow, (unsigned long long)n_shadow);
-    atomicAdd(stats + kStatPaths, (unsigned long long)n_paths);
+    atomicAdd(stats + kStatClosest, (unsigned long long)(n_rays & 0xFFFFu));
+    atomicAdd(stats + kStatShadow, (unsigned long long)(n_rays >> 16));
+    atomicAdd(stats + kStatPaths, (unsigned long long)n_paths_wave);
 }
 
 // ---- wavefront: 64-byte path records as four float4 planes -----------------
@@ -765,8 +769,10 @@ int hpt_render(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sample
 #ifdef HPT_PROFILE
         lds_mega += waves_per_block * 3u * kProfSections * 8u;
 #endif
+        // per-lane ray counters are 16 bits wide: a lane traces at most n * max_depth bounces per launch
+        const uint32_t per_launch = std::max(1u, std::min(ctx->spp_per_launch, 65535u / (uint32_t)max_depth));
         for (uint32_t s = sample_begin; s < sample_begin + sample_count;) {
-            const uint32_t n = (sample_begin + sample_count - s > ctx->spp_per_launch) ? ctx->spp_per_launch : sample_begin + sample_count - s;
+            const uint32_t n = (sample_begin + sample_count - s > per_launch) ? per_launch : sample_begin + sample_count - s;
             HPT_DISPATCH_SCENE(S.variant, {
                 if (block <= 256) hipLaunchKernelGGL((k_render_mega<kS, 256>), dim3(blocks), dim3(block), lds_mega, stream, S, max_depth, s, n, accum, ctx->d_stats);
                 else hipLaunchKernelGGL((k_render_mega<kS, 1024>), dim3(blocks), dim3(block), lds_mega, stream, S, max_depth, s, n, accum, ctx->d_stats);

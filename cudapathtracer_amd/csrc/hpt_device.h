@@ -589,7 +589,7 @@ HD void generate_camera_path(const DevScene& S, uint32_t pixel, uint32_t sample,
 // (hit_tri, hit_t); hit_tri < 0 = miss.  Returns false when the path ends on
 // this bounce for the reason "missed the scene" (remainingBounces = 0, :156-161);
 // the caller ends it after max_depth bounces otherwise.  Counts shadow queries.
-template <int kScene>
+template <int kScene, uint32_t kShadowInc = 1u>
 HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, Path& p, int hit_tri, double hit_t,
                      uint32_t& shadow_queries PROF_ARG) {
     bool alive = true;
@@ -603,18 +603,17 @@ HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, TriQueue
             break;
         }
         // the device copies in global memory (not the LDS stage): word 3 = light pdf
-        const float4 t0 = S.tris[4 * hit_tri], t1 = S.tris[4 * hit_tri + 1], t3 = S.tris[4 * hit_tri + 3];
-        const f3 normal = xyz(t3);
-        const DevMaterial& material = S.mats[__float_as_int(t1.w)];
         const f3 coords = p.o + p.d * (float)hit_t;  // Ray::operator(), Ray.hpp:27
-
-        if (material.flags & kMatEmitting) {  // :164-184
-            const f3 radiance = mk(material.emission[0], material.emission[1], material.emission[2]);
-            if (p.depth == 0 || p.specular) {
-                p.rad = p.rad + p.thr * radiance;
-            } else {
-                const float weight = powerHeuristic(p.pdf, t0.w);
-                p.rad = p.rad + p.thr * radiance * weight;
+        {
+            const DevMaterial& material = S.mats[__float_as_int(S.tris[4 * hit_tri + 1].w)];
+            if (material.flags & kMatEmitting) {  // :164-184
+                const f3 radiance = mk(material.emission[0], material.emission[1], material.emission[2]);
+                if (p.depth == 0 || p.specular) {
+                    p.rad = p.rad + p.thr * radiance;
+                } else {
+                    const float weight = powerHeuristic(p.pdf, S.tris[4 * hit_tri].w);
+                    p.rad = p.rad + p.thr * radiance * weight;
+                }
             }
         }
 
@@ -622,7 +621,8 @@ HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, TriQueue
             // Scene::sampleLight (:99-120)
             const u4 ra = philox4x32_10((uint32_t)p.depth, 0u, S.seed, 0u, p.pixel, p.sample);
             float lightSamplePdf = 0.0f, lightPdf = 0.0f;
-            f3 lx = mk(0.f), ln = mk(0.f), lemit = mk(0.f);
+            f3 lx = mk(0.f), ln = mk(0.f);
+            uint32_t light = 0;
             {
                 const float pick = u01(ra.x) * S.sum_light_area;
                 float emit_area_sum = 0;
@@ -651,23 +651,23 @@ HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, TriQueue
                         ln = xyz(a3);
                         lightPdf = a0.w;
                         lightSamplePdf = L.inv_root_area;
-                        lemit = mk(L.emission[0], L.emission[1], L.emission[2]);
+                        light = k;
                         break;
                     }
                 }
             }
             if (lightSamplePdf > 0.0f) {
-                const f3 wo = -p.d;
                 const f3 px = lx - coords;
                 const f3 wi = normalize(px);
                 const f3 so = coords + wi * kEpsilon5;
-                // everything that depends on the light sample is reduced to scalars here, so
-                // that only they stay live across the shadow traversal
+                // everything that depends on the light sample is reduced to scalars here, and
+                // the hit's normal / material are re-read after the traversal, so that little
+                // stays live in registers across it
                 const float cos_theta_prime = satDot(ln, -wi);
                 const float r2 = dot(lx - coords, lx - coords);
                 int occ_tri;
                 double occ_t;
-                ++shadow_queries;
+                shadow_queries += kShadowInc;
 #ifdef HPT_PROFILE
                 prof_add(prof, kProfShadeA, __builtin_readcyclecounter() - prof_s0);
 #endif
@@ -677,6 +677,12 @@ HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, TriQueue
                 PROF_ITER(kProfShadeB);
 #endif
                 if (occ_tri < 0) {
+                    asm volatile("" : "+v"(hit_tri), "+v"(light));  // forget what was derived from them
+                    const f3 normal = xyz(S.tris[4 * hit_tri + 3]);
+                    const DevMaterial& material = S.mats[__float_as_int(S.tris[4 * hit_tri + 1].w)];
+                    const DevLight& L = S.lights[light];
+                    const f3 lemit = mk(L.emission[0], L.emission[1], L.emission[2]);
+                    const f3 wo = -p.d;
                     f3 bsdf;
                     float bsdfPdf;
                     mat_eval(material, wi, wo, normal, bsdf, bsdfPdf);
@@ -688,6 +694,9 @@ HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, TriQueue
         }
 
         // :230-250
+        asm volatile("" : "+v"(hit_tri));
+        const f3 normal = xyz(S.tris[4 * hit_tri + 3]);
+        const DevMaterial& material = S.mats[__float_as_int(S.tris[4 * hit_tri + 1].w)];
         const u4 rb = philox4x32_10((uint32_t)p.depth, 1u, S.seed, 0u, p.pixel, p.sample);
         const f3 wo = -p.d;
         const f3 wi = mat_sample(material, u01(rb.x), u01(rb.y), wo, normal);
