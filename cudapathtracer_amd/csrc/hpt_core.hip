@@ -34,6 +34,7 @@ using namespace hpt;
 namespace {
 
 constexpr uint32_t kLdsLimit = 32u * 1024u;
+constexpr uint32_t kMaxStackDepth = 40;  // per-lane stack entries (4 B each in LDS); median-split trees need ~log2(triangles)
 constexpr int kStatClosest = 0, kStatShadow = 1, kStatPaths = 2, kNumStats = 4;
 
 thread_local std::string g_last_error;
@@ -72,9 +73,9 @@ __global__ void k_intersect_batch(DevScene S, size_t n, const float* __restrict_
                                   const uint8_t* __restrict__ shadow, const double* __restrict__ tmax,
                                   int32_t* __restrict__ prim, double* __restrict__ t_out) {
     extern __shared__ float4 lds[];
-    if constexpr (kScene != kSceneGlobal) stage_scene_lds<kScene == kSceneTiny32 || kScene == kSceneSweep>(S, lds);
+    stage_scene<kScene>(S, lds);
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    const TriQueue tq{reinterpret_cast<uint32_t*>(lds + S.lds_float4s) + threadIdx.x, blockDim.x};
+    const TriQueue tq = make_tri_queue(reinterpret_cast<uint32_t*>(lds + S.lds_float4s));
 #ifdef HPT_PROFILE
     __shared__ unsigned long long prof_dummy[3 * kProfSections];
     ProfAcc prof;
@@ -123,8 +124,8 @@ k_render_mega(DevScene S, int max_depth, uint32_t s_begin, uint32_t s_count, int
     unsigned long long* tile_acc = reinterpret_cast<unsigned long long*>(lds + S.lds_float4s) + wave * 192u;
     for (uint32_t i = lane; i < 192u; i += wave_lanes) tile_acc[i] = 0ull;
     // triangle queues (variants without a pending mask) lie behind all waves' accumulators
-    const TriQueue tq{reinterpret_cast<uint32_t*>(lds + S.lds_float4s) + waves_per_block * 384u + threadIdx.x, blockDim.x};
-    if constexpr (kScene != kSceneGlobal) stage_scene_lds<kScene == kSceneTiny32 || kScene == kSceneSweep>(S, lds);
+    const TriQueue tq = make_tri_queue(reinterpret_cast<uint32_t*>(lds + S.lds_float4s) + waves_per_block * 384u);
+    stage_scene<kScene>(S, lds);
 
     const uint32_t W = (uint32_t)S.width, H = (uint32_t)S.height;
     const uint32_t tiles_x = (W + 7u) >> 3, tiles_y = (H + 7u) >> 3;
@@ -142,7 +143,7 @@ k_render_mega(DevScene S, int max_depth, uint32_t s_begin, uint32_t s_count, int
         Path p;
 #ifdef HPT_PROFILE
         ProfAcc prof;
-        prof.w = tile_acc + 192u * (waves_per_block - wave) + (kTriQueue * blockDim.x + 1u) / 2u + wave * 3u * kProfSections;  // behind accumulators and queues
+        prof.w = tile_acc + 192u * (waves_per_block - wave) + ((kTriQueue + S.stack_depth) * blockDim.x + 1u) / 2u + wave * 3u * kProfSections;  // behind accumulators and queues
         for (uint32_t i = lane; i < 3u * kProfSections; i += wave_lanes) prof.w[i] = 0ull;
         const unsigned long long prof_start = __builtin_readcyclecounter();
 #endif
@@ -267,10 +268,10 @@ __global__ void __launch_bounds__(256)
 k_wf_extend(DevScene S, WfQueue q, const uint32_t* __restrict__ live_count, int2* __restrict__ hits,
             unsigned long long* __restrict__ stats) {
     extern __shared__ float4 lds[];
-    if constexpr (kScene != kSceneGlobal) stage_scene_lds<kScene == kSceneTiny32 || kScene == kSceneSweep>(S, lds);
+    stage_scene<kScene>(S, lds);
     const uint32_t count = *live_count;
     const uint32_t stride = gridDim.x * blockDim.x;
-    const TriQueue tq{reinterpret_cast<uint32_t*>(lds + S.lds_float4s) + threadIdx.x, blockDim.x};
+    const TriQueue tq = make_tri_queue(reinterpret_cast<uint32_t*>(lds + S.lds_float4s));
     uint32_t n_closest = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
         const float4 a = q.a[i], b = q.b[i];
@@ -300,11 +301,11 @@ k_wf_shade(DevScene S, int max_depth, WfQueue q_in, const int2* __restrict__ hit
            WfQueue q_out, uint32_t* __restrict__ live_out, int64_t* __restrict__ accum,
            unsigned long long* __restrict__ stats) {
     extern __shared__ float4 lds[];
-    if constexpr (kScene != kSceneGlobal) stage_scene_lds<kScene == kSceneTiny32 || kScene == kSceneSweep>(S, lds);
+    stage_scene<kScene>(S, lds);
     const uint32_t count = *live_in;
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t lane = threadIdx.x & 63u;
-    const TriQueue tq{reinterpret_cast<uint32_t*>(lds + S.lds_float4s) + threadIdx.x, blockDim.x};
+    const TriQueue tq = make_tri_queue(reinterpret_cast<uint32_t*>(lds + S.lds_float4s));
     uint32_t n_shadow = 0;
     // all lanes of a wave run the same number of iterations so that the
     // ballot below always sees the whole wave
@@ -355,6 +356,8 @@ __global__ void k_resolve(const int64_t* __restrict__ accum, size_t n, double de
     case kSceneLds: { constexpr int kS = kSceneLds; CALL; } break;                \
     case kSceneTiny32: { constexpr int kS = kSceneTiny32; CALL; } break;          \
     case kSceneTiny64: { constexpr int kS = kSceneTiny64; CALL; } break;          \
+    case kScenePair: { constexpr int kS = kScenePair; CALL; } break;              \
+    case kScenePairLds: { constexpr int kS = kScenePairLds; CALL; } break;        \
     default: { constexpr int kS = kSceneSweep; CALL; } break;                     \
     }
 
@@ -370,6 +373,7 @@ struct hpt_ctx {
     float* d_node_area = nullptr;
     float4* d_tris = nullptr;
     float4* d_tri_v12 = nullptr;
+    float4* d_pairs = nullptr;
     DevMaterial* d_mats = nullptr;
     DevLight* d_lights = nullptr;
     // accumulation + stats
@@ -405,6 +409,7 @@ void free_scene(hpt_ctx* ctx) {
     (void)hipFree(ctx->d_node_area);
     (void)hipFree(ctx->d_tris);
     (void)hipFree(ctx->d_tri_v12);
+    (void)hipFree(ctx->d_pairs);
     (void)hipFree(ctx->d_mats);
     (void)hipFree(ctx->d_lights);
     (void)hipFree(ctx->d_accum);
@@ -413,6 +418,7 @@ void free_scene(hpt_ctx* ctx) {
     ctx->d_node_area = nullptr;
     ctx->d_tris = nullptr;
     ctx->d_tri_v12 = nullptr;
+    ctx->d_pairs = nullptr;
     ctx->d_mats = nullptr;
     ctx->d_lights = nullptr;
     ctx->d_accum = nullptr;
@@ -531,7 +537,9 @@ int settle_events(hpt_ctx* ctx) {
 // dynamic LDS of the traversal kernels: the staged scene (if any) + the per-lane
 // triangle queues of the variants that use them
 uint32_t lds_bytes(const DevScene& S, int block) {
-    return S.lds_float4s * 16u + (S.variant <= kSceneLds ? (uint32_t)block * kTriQueue * 4u : 0u);
+    const bool pair = S.variant == kScenePair || S.variant == kScenePairLds;
+    const bool queue = pair || S.variant == kSceneGlobal || S.variant == kSceneLds;
+    return S.lds_float4s * 16u + (queue ? (uint32_t)block * kTriQueue * 4u : 0u) + (pair ? (uint32_t)block * S.stack_depth * 4u : 0u);
 }
 
 int grid_for(const hpt_ctx* ctx, uint64_t work, int block) {
@@ -669,6 +677,46 @@ int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* sc) {
         HIP_TRY(hipMemcpy(ctx->d_mats, mats.data(), mats.size() * sizeof(DevMaterial), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(ctx->d_lights, lights.data(), lights.size() * sizeof(DevLight), hipMemcpyHostToDevice));
     }
+    // Two-child records of the same tree (see DevScene::pairs).  Interior node i has the children
+    // i + 1 and miss(i + 1); records are numbered in pre-order of the interior nodes.
+    uint32_t num_pairs = 0, stack_depth = 1;
+    {
+        auto node_int = [&](size_t i, int word) {
+            int32_t v;
+            std::memcpy(&v, &sc->nodes[8 * i + word], 4);
+            return v;
+        };
+        std::vector<int32_t> pair_of(nn, -1);
+        for (size_t i = 0; i < nn; ++i)
+            if (node_int(i, 7) < 0) pair_of[i] = (int32_t)num_pairs++;
+        if (num_pairs) {
+            std::vector<float> rec((size_t)num_pairs * 16);
+            std::vector<uint32_t> need(num_pairs, 0);  // stack entries a walk below this record can hold at once
+            for (size_t i = nn; i-- > 0;) {
+                if (pair_of[i] < 0) continue;
+                const size_t l = i + 1, r = (size_t)node_int(l, 3);
+                float* q = &rec[(size_t)pair_of[i] * 16];
+                const int32_t tl = node_int(l, 7), tr = node_int(r, 7);
+                const int32_t ref_l = tl >= 0 ? ~tl : pair_of[l], ref_r = tr >= 0 ? ~tr : pair_of[r];
+                for (int c = 0; c < 3; ++c) {
+                    q[c] = sc->nodes[8 * l + c];
+                    q[4 + c] = sc->nodes[8 * l + 4 + c];
+                    q[8 + c] = sc->nodes[8 * r + c];
+                    q[12 + c] = sc->nodes[8 * r + 4 + c];
+                }
+                std::memcpy(&q[3], &ref_l, 4);
+                std::memcpy(&q[7], &ref_r, 4);
+                q[11] = q[15] = 0.f;
+                // the right child waits on the stack while the left subtree is walked
+                const uint32_t nl = ref_l >= 0 ? need[ref_l] + (ref_r >= 0 ? 1u : 0u) : 0u;
+                const uint32_t nr = ref_r >= 0 ? need[ref_r] : 0u;
+                need[pair_of[i]] = std::max(nl, nr);
+            }
+            stack_depth = std::max(1u, need[0]);
+            HIP_TRY(hipMalloc((void**)&ctx->d_pairs, rec.size() * 4));
+            HIP_TRY(hipMemcpy(ctx->d_pairs, rec.data(), rec.size() * 4, hipMemcpyHostToDevice));
+        }
+    }
     ctx->accum_elems = 3ull * (size_t)sc->width * (size_t)sc->height;
     HIP_TRY(hipMalloc((void**)&ctx->d_accum, ctx->accum_elems * sizeof(int64_t)));
     HIP_TRY(hipMemset(ctx->d_accum, 0, ctx->accum_elems * sizeof(int64_t)));
@@ -698,19 +746,34 @@ int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* sc) {
     S.height = sc->height;
     S.seed = seed;
     S.prof = ctx->d_prof;
-    const uint64_t f4 = 2ull * nn + 4ull * nt;
-    S.lds_float4s = (f4 * 16ull <= kLdsLimit) ? (uint32_t)f4 : 0u;
+    S.pairs = ctx->d_pairs;
+    S.num_pairs = num_pairs;
+    S.stack_depth = stack_depth;
+    for (int c = 0; c < 3; ++c) {
+        S.root_lo[c] = sc->nodes[c];
+        S.root_hi[c] = sc->nodes[4 + c];
+    }
+    const uint64_t f4 = 2ull * nn + 4ull * nt;        // threaded nodes + triangles
+    const uint64_t f4_pair = 4ull * num_pairs + 4ull * nt;  // two-child records + triangles (about the same)
+    const bool fits = f4 * 16ull <= kLdsLimit, fits_pair = f4_pair * 16ull <= kLdsLimit;
+    const bool pair_ok = num_pairs > 0 && stack_depth <= kMaxStackDepth;
     // (the wave-uniform sweep, kSceneSweep, measured slower than the per-lane walk: 17.1 vs 19.1 Grays/s on
     // incoherent rays; it stays selectable with HPT_TRACE_VARIANT=4 for experiments)
-    S.variant = !S.lds_float4s ? kSceneGlobal : (nt <= 32 ? kSceneTiny32 : (nt <= 64 ? kSceneTiny64 : kSceneLds));
-    if (const char* e = getenv("HPT_TRACE_VARIANT")) {  // experiments: force a simpler variant
+    if (fits && nt <= 32) S.variant = kSceneTiny32;
+    else if (fits && nt <= 64) S.variant = kSceneTiny64;
+    else if (pair_ok) S.variant = fits_pair ? kScenePairLds : kScenePair;
+    else S.variant = fits ? kSceneLds : kSceneGlobal;
+    if (const char* e = getenv("HPT_TRACE_VARIANT")) {  // experiments: force another variant
         const int v = atoi(e);
-        if (v == kSceneGlobal) { S.variant = kSceneGlobal; S.lds_float4s = 0; }
-        else if (v == kSceneLds && S.lds_float4s) S.variant = kSceneLds;
-        else if (v == kSceneTiny64 && S.lds_float4s && nt <= 64) S.variant = kSceneTiny64;
-        else if (v == kSceneTiny32 && S.lds_float4s && nt <= 32) S.variant = kSceneTiny32;
-        else if (v == kSceneSweep && S.lds_float4s && nt <= 32 && nn <= kSweepMaxNodes) S.variant = kSceneSweep;
+        if (v == kSceneGlobal) S.variant = kSceneGlobal;
+        else if (v == kSceneLds && fits) S.variant = kSceneLds;
+        else if (v == kSceneTiny64 && fits && nt <= 64) S.variant = kSceneTiny64;
+        else if (v == kSceneTiny32 && fits && nt <= 32) S.variant = kSceneTiny32;
+        else if (v == kSceneSweep && fits && nt <= 32 && nn <= kSweepMaxNodes) S.variant = kSceneSweep;
+        else if (v == kScenePair && pair_ok) S.variant = kScenePair;
+        else if (v == kScenePairLds && pair_ok && fits_pair) S.variant = kScenePairLds;
     }
+    S.lds_float4s = (S.variant == kSceneGlobal || S.variant == kScenePair) ? 0u : (S.variant == kScenePairLds ? (uint32_t)f4_pair : (uint32_t)f4);
     ctx->has_scene = true;
     return HPT_OK;
 }
@@ -908,6 +971,7 @@ int hpt_stats_get(hpt_ctx* ctx, hpt_stats* out) {
     out->paths = h[kStatPaths];
     out->kernel_ms = ctx->kernel_ms;
     out->launches = ctx->launches;
+    out->variant = ctx->has_scene ? (uint32_t)ctx->S.variant : 0u;
 #ifdef HPT_PROFILE
     if (ctx->d_prof) {
         unsigned long long pr[3 * kProfSections];

@@ -215,28 +215,23 @@ struct DevScene {
     float cam_x, cam_y, cam_z, cam_scale, aspect;
     int width, height;
     uint32_t seed;
-    uint32_t lds_float4s;  // > 0: nodes+tris are staged into LDS (2*num_nodes + 4*num_tris float4)
-    int32_t variant;       // kSceneGlobal .. kSceneTiny64
+    uint32_t lds_float4s;  // > 0: that many float4 of node (or pair) + triangle records are staged into LDS
+    int32_t variant;       // kSceneGlobal .. kScenePairLds
+    // two-child records of the same tree (variants kScenePair / kScenePairLds), 4 x float4 per
+    // interior node, in pre-order:
+    //   (left.pMin, left ref) (left.pMax, right ref) (right.pMin, -) (right.pMax, -)
+    // ref >= 0: index of the child's own record; ref < 0: the child is a leaf, triangle ~ref
+    const float4* pairs;
+    uint32_t num_pairs;
+    uint32_t stack_depth;  // entries of the per-lane traversal stack that no ray can exceed
+    float root_lo[3], root_hi[3];  // bounds of node 0
     unsigned long long* prof;  // diagnostic builds only (3 x kProfSections totals), else null
 };
 
-// Stage the node and triangle records into LDS (tiny scenes: the Cornell box is
+// Stage the scene records a variant reads from LDS (tiny scenes: the Cornell box is
 // 63 nodes + 32 triangles = 4 KiB).  Every thread of the workgroup must call it.
-template <bool kLeafBits>
-HD void stage_scene_lds(const DevScene& S, float4* lds) {
-    const uint32_t nn = 2u * S.num_nodes, nt = 4u * S.num_tris;
-    for (uint32_t i = threadIdx.x; i < nn; i += blockDim.x) {
-        float4 v = S.nodes[i];
-        if (kLeafBits && (i & 1u)) {  // pMax half: triangle index -> its bit in the pending mask (0 = interior)
-            const int tri = __float_as_int(v.w);
-            v.w = __uint_as_float(tri >= 0 ? 1u << tri : 0u);
-        }
-        lds[i] = v;
-    }
-    for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) lds[nn + i] = S.tris[i];
-    __syncthreads();
-}
-
+template <int kScene>
+HD void stage_scene(const DevScene& S, float4* lds);
 // ------------------------------------------------------------ traversal -----
 // Scene residency / traversal variant, chosen at upload from the scene size:
 enum {
@@ -246,6 +241,10 @@ enum {
     kSceneTiny64 = 3,  // leaves it reaches (one bit each, 32- or 64-bit mask per lane); the
                        // triangle tests run afterwards in a loop of their own, so lanes that
                        // are at interior nodes never idle through another lane's triangle test
+    kScenePair = 5,    // larger scenes: two-child records (64 B: both children's boxes), depth-first
+    kScenePairLds = 6, // with a per-lane stack in LDS; one dependent fetch per two box tests.
+                       // Records read through L1/L2 (5) or staged in LDS (6).  Same box tests,
+                       // same leaves reached as the threaded walk, in a different order.
     kSceneSweep = 4    // <= 32 triangles and <= kSweepMaxNodes nodes: as Tiny32, but the box phase
                        // is a wave-uniform sweep over ALL nodes in pre-order: the node record is
                        // fetched once per wave with scalar loads (operands in SGPRs, no LDS access,
@@ -253,6 +252,31 @@ enum {
                        // walk would be there.  Same tests per lane, no load latency on the walk.
 };
 constexpr uint32_t kSweepMaxNodes = 96;
+
+template <int kScene>
+HD void stage_scene(const DevScene& S, float4* lds) {
+    if constexpr (kScene == kSceneGlobal || kScene == kScenePair) {
+        return;
+    } else if constexpr (kScene == kScenePairLds) {
+        const uint32_t np = 4u * S.num_pairs, nt = 4u * S.num_tris;
+        for (uint32_t i = threadIdx.x; i < np; i += blockDim.x) lds[i] = S.pairs[i];
+        for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) lds[np + i] = S.tris[i];
+        __syncthreads();
+    } else {
+        constexpr bool kLeafBits = (kScene == kSceneTiny32 || kScene == kSceneSweep);
+        const uint32_t nn = 2u * S.num_nodes, nt = 4u * S.num_tris;
+        for (uint32_t i = threadIdx.x; i < nn; i += blockDim.x) {
+            float4 v = S.nodes[i];
+            if (kLeafBits && (i & 1u)) {  // pMax half: triangle index -> its bit in the pending mask (0 = interior)
+                const int tri = __float_as_int(v.w);
+                v.w = __uint_as_float(tri >= 0 ? 1u << tri : 0u);
+            }
+            lds[i] = v;
+        }
+        for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) lds[nn + i] = S.tris[i];
+        __syncthreads();
+    }
+}
 
 // Bounds3::IntersectP (common/Bounds3.hpp:93-118): float slab test, no t-range
 // culling, every comparison false on NaN.
@@ -319,13 +343,24 @@ constexpr uint32_t kTriQueue = 8;
 struct TriQueue {
     uint32_t* q;
     uint32_t stride;
+    uint32_t* stk;  // traversal stack of the pair variants: entry k of a lane at stk[k * stride]
 };
+// the per-lane LDS scratch of a workgroup starts at `base` (queues of all lanes, then stacks)
+HD TriQueue make_tri_queue(uint32_t* base) {
+    return TriQueue{base + threadIdx.x, blockDim.x, base + kTriQueue * blockDim.x + threadIdx.x};
+}
 
 template <int kScene, bool kShadow>
 HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3 o, f3 d, double tmax, int& hit_tri, double& hit_t PROF_ARG) {
     const float4* N;
     const float4* T;
-    if constexpr (kScene != kSceneGlobal) {
+    if constexpr (kScene == kScenePairLds) {
+        N = lds;  // pair records
+        T = lds + 4u * S.num_pairs;
+    } else if constexpr (kScene == kScenePair) {
+        N = S.pairs;
+        T = S.tris;
+    } else if constexpr (kScene != kSceneGlobal) {
         N = lds;
         T = lds + 2u * S.num_nodes;
     } else {
@@ -425,8 +460,81 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
             }
         }
         PROF_T1(kShadow ? kProfTriS : kProfTriC);  // filter + tests (includes the box time, subtracted by the reader)
+    } else if constexpr (kScene == kScenePair || kScene == kScenePairLds) {
+        // Depth-first over two-child records.  A record is visited iff its node's box was hit,
+        // and both children's boxes are tested there: the same tests as the threaded walk makes
+        // (it tests a node iff its parent was hit).  Leaves reached are queued and tested in a
+        // loop of their own; the visit order differs from the reference's, so the closest-hit
+        // update spells out its tie rule: among equal t the triangle visited first by the
+        // reference (= lowest index, triangles are stored in its visit order) wins.
+        const float kInf = __builtin_inff();
+        const bool finite = fabsf(inv.x) < kInf && fabsf(inv.y) < kInf && fabsf(inv.z) < kInf;
+        const float4 rlo = make_float4(S.root_lo[0], S.root_lo[1], S.root_lo[2], 0.f);
+        const float4 rhi = make_float4(S.root_hi[0], S.root_hi[1], S.root_hi[2], 0.f);
+        int cur = (finite ? box_hit_finite(rlo, rhi, o, inv) : box_hit(rlo, rhi, o, inv, nx, ny, nz)) ? 0 : -1;
+        uint32_t cnt = 0, sp = 0;
+        for (;;) {
+            while (cur >= 0 && cnt + 2u <= kTriQueue) {
+                const float4 q0 = N[4 * cur], q1 = N[4 * cur + 1], q2 = N[4 * cur + 2], q3 = N[4 * cur + 3];
+                bool hl, hr;
+                if (finite) {
+                    hl = box_hit_finite(q0, q1, o, inv);
+                    hr = box_hit_finite(q2, q3, o, inv);
+                } else {
+                    hl = box_hit(q0, q1, o, inv, nx, ny, nz);
+                    hr = box_hit(q2, q3, o, inv, nx, ny, nz);
+                }
+                const int rl = __float_as_int(q0.w), rr = __float_as_int(q1.w);
+                if (hl && rl < 0) {
+                    tq.q[cnt * tq.stride] = (uint32_t)~rl;
+                    ++cnt;
+                }
+                if (hr && rr < 0) {
+                    tq.q[cnt * tq.stride] = (uint32_t)~rr;
+                    ++cnt;
+                }
+                const bool gl = hl && rl >= 0, gr = hr && rr >= 0;
+                if (gl) {
+                    if (gr) {
+                        tq.stk[sp * tq.stride] = (uint32_t)rr;
+                        ++sp;
+                    }
+                    cur = rl;
+                } else if (gr) {
+                    cur = rr;
+                } else if (sp) {
+                    --sp;
+                    cur = (int)tq.stk[sp * tq.stride];
+                } else {
+                    cur = -1;
+                }
+            }
+            if (cnt == 0) break;
+            for (uint32_t k = 0; k < cnt; ++k) {
+                const int tri = (int)tq.q[k * tq.stride];
+                double t;
+                if (tri_hit(T, tri, o, d, t)) {
+                    if constexpr (kShadow) {
+                        if (t < limit) {
+                            best = tri;
+                            best_t = t;
+                            cur = -1;
+                            break;
+                        }
+                    } else {
+                        if (t < best_t || (t == best_t && tri < best)) {
+                            best = tri;
+                            best_t = t;
+                        }
+                    }
+                }
+            }
+            cnt = 0;
+            if (cur < 0) break;
+        }
     } else {
-        // Larger scenes: the box walk queues the triangles of the leaves it reaches
+        // Threaded walk with queued triangle tests (kept for trees whose depth exceeds the stack
+        // budget, and for comparison): the box walk queues the triangles of the leaves it reaches
         // (up to kTriQueue per lane) and the tests run in a loop of their own, in
         // queue order = visit order, so the strict `<` update sees the reference's
         // sequence.  A lane whose queue is full waits for the flush.

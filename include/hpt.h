@@ -108,9 +108,11 @@ typedef struct {
     uint64_t closest_queries; /* closest-hit BVH queries  */
     uint64_t shadow_queries;  /* any-hit (shadow) queries */
     uint64_t paths;           /* camera paths started     */
-    double kernel_ms;         /* HIP-event time of the render kernels of the last hpt_render */
-    uint32_t launches;        /* kernel launches of the last hpt_render                      */
-    uint32_t _pad;
+    double kernel_ms;         /* HIP-event time of hpt_render's kernels, summed since the last hpt_stats_reset */
+    uint32_t launches;        /* kernel launches of hpt_render, summed since the last hpt_stats_reset        */
+    uint32_t variant;         /* traversal variant chosen for the uploaded scene: 0 threaded walk through L1/L2,
+                                 1 the same from LDS, 2/3 LDS with a 32-/64-bit leaf mask, 4 wave-uniform sweep,
+                                 5 two-child records + stack through L1/L2, 6 the same from LDS */
 } hpt_stats;
 
 const char* hpt_last_error(void);
@@ -178,8 +180,8 @@ int hpt_intersect_batch(hpt_ctx* ctx, size_t n, const float* o, const float* d, 
 int hpt_intersect_batch_dev(hpt_ctx* ctx, size_t n, const float* o_dev, const float* d_dev, const uint8_t* shadow_dev,
                             const double* tmax_dev, int32_t* prim_dev, double* t_dev, int block, void* stream);
 
-/* Ray counters accumulated since the last hpt_stats_reset, timing of the last
- * hpt_render.  Synchronises the device. */
+/* Ray counters, kernel time and launch count accumulated since the last
+ * hpt_stats_reset.  Synchronises the device. */
 int hpt_stats_get(hpt_ctx* ctx, hpt_stats* out);
 int hpt_stats_reset(hpt_ctx* ctx);
 
