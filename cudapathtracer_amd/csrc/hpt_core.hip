@@ -68,6 +68,13 @@ __device__ __forceinline__ bool lane_to_pixel(const DevScene& S, uint32_t g, uin
     return x < (uint32_t)S.width && y < (uint32_t)S.height;
 }
 
+// counters: one atomic per wave (every lane adding to the same address would serialise in L2)
+__device__ __forceinline__ void stat_add(unsigned long long* slot, uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63u) == 0u && v) atomicAdd(slot, (unsigned long long)v);
+}
+
 template <int kScene>
 __global__ void k_intersect_batch(DevScene S, size_t n, const float* __restrict__ o, const float* __restrict__ d,
                                   const uint8_t* __restrict__ shadow, const double* __restrict__ tmax,
@@ -198,9 +205,9 @@ k_render_mega(DevScene S, int max_depth, uint32_t s_begin, uint32_t s_count, int
             atomicAdd(out + 3ull * pix + 2ull, tile_acc[3u * j + 2u]);
         }
     }
-    atomicAdd(stats + kStatClosest, (unsigned long long)(n_rays & 0xFFFFu));
-    atomicAdd(stats + kStatShadow, (unsigned long long)(n_rays >> 16));
-    atomicAdd(stats + kStatPaths, (unsigned long long)n_paths_wave);
+    stat_add(stats + kStatClosest, n_rays & 0xFFFFu);
+    stat_add(stats + kStatShadow, n_rays >> 16);
+    stat_add(stats + kStatPaths, n_paths_wave);
 }
 
 // ---- wavefront: 64-byte path records as four float4 planes -----------------
@@ -259,7 +266,7 @@ __global__ void k_wf_generate(DevScene S, uint32_t s_begin, uint64_t first, uint
         wf_store(q, i, p);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) *live_count = count;
-    atomicAdd(stats + kStatPaths, (unsigned long long)made);
+    stat_add(stats + kStatPaths, made);
 }
 
 // ComputeIntersections (gpu_path_tracer/CudaPathTrace.cu:64-78)
@@ -268,8 +275,9 @@ __global__ void __launch_bounds__(256)
 k_wf_extend(DevScene S, WfQueue q, const uint32_t* __restrict__ live_count, int2* __restrict__ hits,
             unsigned long long* __restrict__ stats) {
     extern __shared__ float4 lds[];
-    stage_scene<kScene>(S, lds);
     const uint32_t count = *live_count;
+    if (blockIdx.x * blockDim.x >= count) return;  // late bounces: most workgroups have no path left
+    stage_scene<kScene>(S, lds);
     const uint32_t stride = gridDim.x * blockDim.x;
     const TriQueue tq = make_tri_queue(reinterpret_cast<uint32_t*>(lds + S.lds_float4s));
     uint32_t n_closest = 0;
@@ -288,7 +296,7 @@ k_wf_extend(DevScene S, WfQueue q, const uint32_t* __restrict__ live_count, int2
         }
         hits[i] = make_int2(tri, __float_as_int((float)t));
     }
-    atomicAdd(stats + kStatClosest, (unsigned long long)n_closest);
+    stat_add(stats + kStatClosest, n_closest);
 }
 
 // IntegratePathSegment + the two thrust compactions + FinalGather
@@ -301,8 +309,9 @@ k_wf_shade(DevScene S, int max_depth, WfQueue q_in, const int2* __restrict__ hit
            WfQueue q_out, uint32_t* __restrict__ live_out, int64_t* __restrict__ accum,
            unsigned long long* __restrict__ stats) {
     extern __shared__ float4 lds[];
-    stage_scene<kScene>(S, lds);
     const uint32_t count = *live_in;
+    if (blockIdx.x * blockDim.x >= count) return;
+    stage_scene<kScene>(S, lds);
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t lane = threadIdx.x & 63u;
     const TriQueue tq = make_tri_queue(reinterpret_cast<uint32_t*>(lds + S.lds_float4s));
@@ -338,7 +347,7 @@ k_wf_shade(DevScene S, int max_depth, WfQueue q_in, const int2* __restrict__ hit
             if (keep) wf_store(q_out, slot + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)), p);
         }
     }
-    atomicAdd(stats + kStatShadow, (unsigned long long)n_shadow);
+    stat_add(stats + kStatShadow, n_shadow);
 }
 
 __global__ void k_resolve(const int64_t* __restrict__ accum, size_t n, double denom, float* __restrict__ rgb) {

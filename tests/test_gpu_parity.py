@@ -143,10 +143,14 @@ def test_block_sizes_give_identical_images(hp, oracle, gpu_ctx, block, mode):
     osc = oracle.cornell(w + 3, h + 5)
     gpu_ctx.upload(sc)
     gpu_ctx.accum_clear()
+    gpu_ctx.stats_reset()
     gpu_ctx.render(mode, block, depth, 0, spp)
     got = gpu_ctx.resolve(spp)
-    want_acc, _ = osc.render(RNG_PHILOX, TRIG_PORTABLE, depth, spp, fixed=True)
+    want_acc, ost = osc.render(RNG_PHILOX, TRIG_PORTABLE, depth, spp, fixed=True)
     assert np.array_equal(got.view(np.int32), oracle.resolve(want_acc, spp).view(np.int32))
+    st = gpu_ctx.stats()    # counters are reduced per wave: a partial last wave (block 100) must count right
+    assert (st["closest_queries"], st["shadow_queries"], st["paths"]) == \
+        (ost["closest_queries"], ost["shadow_queries"], ost["paths"])
 
 
 def test_cpp_hiprenderer_equals_c_abi(hp, oracle, gpu_ctx):
