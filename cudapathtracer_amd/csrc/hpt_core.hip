@@ -122,8 +122,8 @@ __device__ __forceinline__ void accumulate_pixel(int64_t* accum, uint32_t pixel,
 // any pixel of the tile); the tile is added to the global buffer once at the end.
 template <int kScene, int kMaxBlock>
 __global__ void __launch_bounds__(kMaxBlock, (kMaxBlock == 256 ? HPT_MEGA_WAVES : 1))
-k_render_mega(DevScene S, int max_depth, uint32_t s_begin, uint32_t s_count, int64_t* __restrict__ accum,
-              unsigned long long* __restrict__ stats) {
+k_render_mega(DevScene S, int max_depth, uint32_t s_begin_all, uint32_t s_count_all, uint32_t s_chunk, uint32_t n_units,
+              int64_t* __restrict__ accum, unsigned long long* __restrict__ stats) {
     extern __shared__ float4 lds[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t waves_per_block = (blockDim.x + 63u) >> 6;
@@ -136,11 +136,18 @@ k_render_mega(DevScene S, int max_depth, uint32_t s_begin, uint32_t s_count, int
 
     const uint32_t W = (uint32_t)S.width, H = (uint32_t)S.height;
     const uint32_t tiles_x = (W + 7u) >> 3, tiles_y = (H + 7u) >> 3;
-    const uint32_t tile = blockIdx.x * waves_per_block + wave;  // wave-uniform
+    // Work unit of this wave = (tile, chunk of s_chunk samples); units are numbered chunk-major, so
+    // the chunks of an expensive tile start at different times of the launch and the launch's tail
+    // is a fraction of one chunk, not of one tile's whole sample range.
+    const uint32_t unit = blockIdx.x * waves_per_block + wave;  // wave-uniform
+    const uint32_t tile = unit % (tiles_x * tiles_y), chunk = unit / (tiles_x * tiles_y);
+    const uint32_t s_begin = s_begin_all + chunk * s_chunk;
+    // n_units = tiles * ceil(s_count_all / s_chunk): for unit < n_units the chunk starts inside the range
+    const uint32_t s_count = min(s_chunk, s_count_all - chunk * s_chunk);
     // closest queries in the low, shadow queries in the high 16 bits: one register per lane
-    // (a lane runs at most spp_per_launch * max_depth <= 65535 bounces per launch, checked by the host)
+    // (a lane runs at most (s_chunk + 1) * max_depth <= 65535 bounces per launch, checked by the host)
     uint32_t n_rays = 0, n_paths_wave = 0;
-    if (tile < tiles_x * tiles_y) {
+    if (unit < n_units) {
         const uint32_t x0 = (tile % tiles_x) * 8u, y0 = (tile / tiles_x) * 8u;
         const uint32_t vw = min(8u, W - x0), vh = min(8u, H - y0), nv = vw * vh;  // pixels of an edge tile
         const uint32_t total = nv * s_count;
@@ -403,7 +410,8 @@ struct hpt_ctx {
     std::vector<hipEvent_t> free_events;
     double kernel_ms = 0.0;
     uint32_t launches = 0;
-    uint32_t spp_per_launch = 256;  // samples per pixel per single-kernel launch (HPT_SPP_PER_LAUNCH)
+    uint32_t spp_per_launch = 0;    // samples per pixel per single-kernel launch (HPT_SPP_PER_LAUNCH); 0 = about 2^28 paths
+    uint32_t spp_per_unit = 32;     // samples per pixel per wave work unit (HPT_SPP_PER_UNIT)
 };
 
 namespace {
@@ -590,6 +598,10 @@ int hpt_context_create(int device, hpt_ctx** out) {
     if (const char* e = getenv("HPT_SPP_PER_LAUNCH")) {
         int v = atoi(e);
         if (v > 0) ctx->spp_per_launch = (uint32_t)v;
+    }
+    if (const char* e = getenv("HPT_SPP_PER_UNIT")) {
+        int v = atoi(e);
+        if (v > 0) ctx->spp_per_unit = (uint32_t)v;
     }
     hipError_t e = hipMalloc((void**)&ctx->d_stats, kNumStats * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(ctx->d_stats, 0, kNumStats * sizeof(unsigned long long));
@@ -819,7 +831,7 @@ int hpt_render(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sample
     if (!ctx || !ctx->has_scene) return fail(HPT_ERR_NO_SCENE, "no scene uploaded");
     if (mode != HPT_MODE_SINGLE_KERNEL && mode != HPT_MODE_STREAMED) return fail(HPT_ERR_INVALID_ARGUMENT, "mode must be 1 or 2, got %d", mode);
     if (block < 1 || block > 1024) return fail(HPT_ERR_INVALID_ARGUMENT, "block size %d not in [1, 1024]", block);
-    if (max_depth < 0 || max_depth > (1 << 20)) return fail(HPT_ERR_INVALID_ARGUMENT, "bad max_depth %d", max_depth);
+    if (max_depth < 0 || max_depth > 16384) return fail(HPT_ERR_INVALID_ARGUMENT, "max_depth %d not in [0, 16384]", max_depth);
     if ((uint64_t)sample_begin + sample_count > 0xFFFFFFFFull) return fail(HPT_ERR_INVALID_ARGUMENT, "sample range overflows 32 bits");
     if (int rc = set_device(ctx)) return rc;
     hipStream_t stream = (hipStream_t)stream_;
@@ -836,18 +848,26 @@ int hpt_render(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sample
 
     if (mode == HPT_MODE_SINGLE_KERNEL) {
         const uint32_t waves_per_block = ((uint32_t)block + 63u) >> 6;
-        const uint32_t blocks = (tiles + waves_per_block - 1u) / waves_per_block;
         uint32_t lds_mega = lds + waves_per_block * 192u * 8u + (lds_bytes(S, block) - lds);  // + per-wave tile accumulators + queues
 #ifdef HPT_PROFILE
         lds_mega += waves_per_block * 3u * kProfSections * 8u;
 #endif
-        // per-lane ray counters are 16 bits wide: a lane traces at most n * max_depth bounces per launch
-        const uint32_t per_launch = std::max(1u, std::min(ctx->spp_per_launch, 65535u / (uint32_t)max_depth));
+        // per-lane ray counters are 16 bits wide: while its pool is not empty a wave's 64 lanes all
+        // advance, so a unit of c samples runs at most (c + 1) * max_depth loop iterations
+        const uint32_t chunk = std::max(1u, std::min(ctx->spp_per_unit, 65535u / (uint32_t)max_depth - 1u));
+        // at most 2^22 units per launch (the grid stays far below 2^31 lanes)
+        const uint32_t max_chunks = std::max(1u, (1u << 22) / tiles);
+        // launches of about 2^28 paths (256 spp at 1024x1024: ~0.25 s on the Cornell box) amortise the
+        // launch's tail without running one kernel for many seconds on heavy scenes
+        const uint32_t want = ctx->spp_per_launch ? ctx->spp_per_launch : std::max(1u, (1u << 22) / tiles);
+        const uint32_t per_launch = std::max(1u, std::min(want, chunk * max_chunks));
         for (uint32_t s = sample_begin; s < sample_begin + sample_count;) {
             const uint32_t n = (sample_begin + sample_count - s > per_launch) ? per_launch : sample_begin + sample_count - s;
+            const uint32_t units = tiles * ((n + chunk - 1u) / chunk);
+            const uint32_t blocks = (units + waves_per_block - 1u) / waves_per_block;
             HPT_DISPATCH_SCENE(S.variant, {
-                if (block <= 256) hipLaunchKernelGGL((k_render_mega<kS, 256>), dim3(blocks), dim3(block), lds_mega, stream, S, max_depth, s, n, accum, ctx->d_stats);
-                else hipLaunchKernelGGL((k_render_mega<kS, 1024>), dim3(blocks), dim3(block), lds_mega, stream, S, max_depth, s, n, accum, ctx->d_stats);
+                if (block <= 256) hipLaunchKernelGGL((k_render_mega<kS, 256>), dim3(blocks), dim3(block), lds_mega, stream, S, max_depth, s, n, chunk, units, accum, ctx->d_stats);
+                else hipLaunchKernelGGL((k_render_mega<kS, 1024>), dim3(blocks), dim3(block), lds_mega, stream, S, max_depth, s, n, chunk, units, accum, ctx->d_stats);
             })
             HIP_TRY(hipGetLastError());
             ++launches;

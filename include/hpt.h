@@ -155,6 +155,7 @@ int hpt_accum_clear(hpt_ctx* ctx, int64_t* accum_dev, void* stream);
  * a sample range over calls, streams or GPUs yields the same sums.
  *   mode:  HPT_MODE_SINGLE_KERNEL | HPT_MODE_STREAMED
  *   block: workgroup size (the CLI's <threads>), 1..1024
+ *   max_depth: Scene::maxDepth, 0..16384
  * Asynchronous with respect to the host (work is queued on `stream`). */
 int hpt_render(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sample_begin, uint32_t sample_count,
                int64_t* accum_dev, void* stream);

@@ -153,6 +153,25 @@ def test_block_sizes_give_identical_images(hp, oracle, gpu_ctx, block, mode):
         (ost["closest_queries"], ost["shadow_queries"], ost["paths"])
 
 
+def test_sample_chunks_and_spare_waves(hp, oracle, gpu_ctx):
+    """mode 1 splits a launch into (tile, chunk of 32 samples) units: 70 samples = chunks of 32, 32, 6;
+    15 tiles x 3 chunks = 45 units on workgroups of 2 waves leaves one wave without a unit."""
+    w, h, depth, spp = 40, 24, 4, 70
+    sc = hp.Scene.CreateBuiltinScene(hp.Scene.CornellBox, depth, w, h)
+    osc = oracle.cornell(w, h)
+    gpu_ctx.upload(sc)
+    want_acc, ost = osc.render(RNG_PHILOX, TRIG_PORTABLE, depth, spp, fixed=True)
+    for block in (128, 1024):
+        gpu_ctx.accum_clear()
+        gpu_ctx.stats_reset()
+        gpu_ctx.render(1, block, depth, 0, spp)
+        got = gpu_ctx.resolve(spp)
+        st = gpu_ctx.stats()
+        assert (st["closest_queries"], st["shadow_queries"], st["paths"]) == \
+            (ost["closest_queries"], ost["shadow_queries"], ost["paths"])
+        assert np.array_equal(got.view(np.int32), oracle.resolve(want_acc, spp).view(np.int32))
+
+
 def test_cpp_hiprenderer_equals_c_abi(hp, oracle, gpu_ctx):
     """the C++ HipRenderer class (PrepareRender/Render/FinishRender) and the Python mirror."""
     w = h = 64
