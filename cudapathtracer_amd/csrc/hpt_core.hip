@@ -113,108 +113,154 @@ __device__ __forceinline__ void accumulate_pixel(int64_t* accum, uint32_t pixel,
 #ifndef HPT_MEGA_WAVES
 #define HPT_MEGA_WAVES 4
 #endif
-// Mode 1.  One wave owns one 8x8 pixel tile and traces `s_count` samples of each
-// of its pixels.  The tile's (pixel, sample) work items form a pool that the
-// lanes draw from: a lane whose path has ended takes the next item (ballot +
-// prefix count, no atomics), so all 64 lanes stay busy until the pool is empty
-// although path lengths vary from 1 to max_depth bounces.  Finished paths add
-// their fixed-point radiance to per-wave LDS accumulators (any lane may finish
-// any pixel of the tile); the tile is added to the global buffer once at the end.
+// Mode 1.  Persistent waves.  A work unit is (8x8 pixel tile, chunk of s_chunk samples); waves
+// draw unit numbers from a global counter until it runs past n_units.  The (pixel, sample) items
+// of a wave's current unit form a pool that its lanes draw from: a lane whose path has ended
+// takes the next item (ballot + prefix count), so all 64 lanes stay busy although path lengths
+// vary from 1 to max_depth bounces.  When the pool runs dry the wave opens its next unit at
+// once and fills idle lanes from it while the last paths of the previous unit finish: paths of
+// two units (`cur`, `old`) can be in flight, each unit with its own 64-pixel accumulator in LDS
+// (any lane may finish any pixel of its tile); a unit's accumulator is added to the global
+// buffer when its last path has ended.  Units are numbered chunk-major, so the chunks of an
+// expensive tile are spread over the launch.
 template <int kScene, int kMaxBlock>
 __global__ void __launch_bounds__(kMaxBlock, (kMaxBlock == 256 ? HPT_MEGA_WAVES : 1))
 k_render_mega(DevScene S, int max_depth, uint32_t s_begin_all, uint32_t s_count_all, uint32_t s_chunk, uint32_t n_units,
-              int64_t* __restrict__ accum, unsigned long long* __restrict__ stats) {
+              int64_t* __restrict__ accum, unsigned long long* __restrict__ stats, uint32_t* __restrict__ unit_counter) {
     extern __shared__ float4 lds[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t waves_per_block = (blockDim.x + 63u) >> 6;
     const uint32_t wave_lanes = min(64u, blockDim.x - wave * 64u);  // the last wave of an odd-sized block is partial
-    unsigned long long* tile_acc = reinterpret_cast<unsigned long long*>(lds + S.lds_float4s) + wave * 192u;
-    for (uint32_t i = lane; i < 192u; i += wave_lanes) tile_acc[i] = 0ull;
-    // triangle queues (variants without a pending mask) lie behind all waves' accumulators
-    const TriQueue tq = make_tri_queue(reinterpret_cast<uint32_t*>(lds + S.lds_float4s) + waves_per_block * 384u);
+    // two accumulators (unit generations 0 / 1) of 64 pixels x RGB per wave
+    unsigned long long* tile_acc = reinterpret_cast<unsigned long long*>(lds + S.lds_float4s) + wave * 384u;
+    for (uint32_t i = lane; i < 384u; i += wave_lanes) tile_acc[i] = 0ull;
+    // triangle queues / stacks (variants that use them) lie behind all waves' accumulators
+    const TriQueue tq = make_tri_queue(reinterpret_cast<uint32_t*>(lds + S.lds_float4s) + waves_per_block * 768u);
     stage_scene<kScene>(S, lds);
 
     const uint32_t W = (uint32_t)S.width, H = (uint32_t)S.height;
-    const uint32_t tiles_x = (W + 7u) >> 3, tiles_y = (H + 7u) >> 3;
-    // Work unit of this wave = (tile, chunk of s_chunk samples); units are numbered chunk-major, so
-    // the chunks of an expensive tile start at different times of the launch and the launch's tail
-    // is a fraction of one chunk, not of one tile's whole sample range.
-    const uint32_t unit = blockIdx.x * waves_per_block + wave;  // wave-uniform
-    const uint32_t tile = unit % (tiles_x * tiles_y), chunk = unit / (tiles_x * tiles_y);
-    const uint32_t s_begin = s_begin_all + chunk * s_chunk;
-    // n_units = tiles * ceil(s_count_all / s_chunk): for unit < n_units the chunk starts inside the range
-    const uint32_t s_count = min(s_chunk, s_count_all - chunk * s_chunk);
-    // closest queries in the low, shadow queries in the high 16 bits: one register per lane
-    // (a lane runs at most (s_chunk + 1) * max_depth <= 65535 bounces per launch, checked by the host)
+    const uint32_t tiles_x = (W + 7u) >> 3, n_tiles = tiles_x * ((H + 7u) >> 3);
+    unsigned long long* out = reinterpret_cast<unsigned long long*>(accum);
+    // add a finished unit's accumulator to the image and clear it for the unit after next
+    auto flush = [&](unsigned long long* acc, uint32_t x0, uint32_t y0, uint32_t vw, uint32_t nv) {
+        for (uint32_t j = lane; j < nv; j += wave_lanes) {
+            const unsigned long long pix = (unsigned long long)(y0 + j / vw) * W + x0 + j % vw;
+            for (uint32_t c = 0; c < 3u; ++c) {
+                const unsigned long long v = acc[3u * j + c];
+                if (v) atomicAdd(out + 3ull * pix + c, v);
+                acc[3u * j + c] = 0ull;
+            }
+        }
+    };
+    // wave-uniform unit state: the unit whose pool is being handed out, and the one before it
+    uint32_t cur_x0 = 0, cur_y0 = 0, cur_vw = 1, cur_nv = 0, cur_s0 = 0, cur_total = 0, cur_next = 0;
+    uint32_t old_x0 = 0, old_y0 = 0, old_vw = 1, old_nv = 0;
+    bool cur_open = false, old_open = false, queue_empty = false;
+    uint32_t gen = 0;  // accumulator of `cur`; `old` uses the other one
+    // per lane: closest queries in the low, shadow queries in the high 16 bits of one register,
+    // added to the global counters whenever the wave opens a unit (a wave runs at most
+    // (s_chunk + 2) * max_depth <= 65535 loop iterations between two openings, checked by the host)
     uint32_t n_rays = 0, n_paths_wave = 0;
-    if (unit < n_units) {
-        const uint32_t x0 = (tile % tiles_x) * 8u, y0 = (tile / tiles_x) * 8u;
-        const uint32_t vw = min(8u, W - x0), vh = min(8u, H - y0), nv = vw * vh;  // pixels of an edge tile
-        const uint32_t total = nv * s_count;
-        uint32_t next = 0;  // same value in every lane
-        uint32_t slot = 0;
-        bool alive = false;
-        Path p;
+    uint32_t slot = 0, lane_gen = 0;
+    bool alive = false;
+    Path p;
 #ifdef HPT_PROFILE
-        ProfAcc prof;
-        prof.w = tile_acc + 192u * (waves_per_block - wave) + ((kTriQueue + S.stack_depth) * blockDim.x + 1u) / 2u + wave * 3u * kProfSections;  // behind accumulators and queues
-        for (uint32_t i = lane; i < 3u * kProfSections; i += wave_lanes) prof.w[i] = 0ull;
-        const unsigned long long prof_start = __builtin_readcyclecounter();
+    ProfAcc prof;
+    prof.w = tile_acc + 384u * (waves_per_block - wave) + ((kTriQueue + S.stack_depth) * blockDim.x + 1u) / 2u + wave * 3u * kProfSections;  // behind accumulators and queues
+    for (uint32_t i = lane; i < 3u * kProfSections; i += wave_lanes) prof.w[i] = 0ull;
+    const unsigned long long prof_start = __builtin_readcyclecounter();
 #endif
-        for (;;) {
-            PROF_ITER(kProfDone);
-            const unsigned long long need = __ballot(!alive);
-            if (need) {
-                const uint32_t k = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
-                next += (uint32_t)__popcll(need);
-                if (!alive && k < total) {
+    for (;;) {
+        PROF_ITER(kProfDone);
+        const unsigned long long need = __ballot(!alive);
+        if (need) {
+            if (!(cur_open && cur_next < cur_total) && !queue_empty) {
+                // pool exhausted: retire `old` once its paths have ended, then open the next unit
+                const bool old_busy = old_open && __ballot(alive && lane_gen != gen) != 0ull;
+                if (!old_busy) {
+                    if (old_open) {
+                        flush(tile_acc + (gen ^ 1u) * 192u, old_x0, old_y0, old_vw, old_nv);
+                        old_open = false;
+                    }
+                    uint32_t u = 0;
+                    if (lane == 0) u = atomicAdd(unit_counter, 1u);
+                    u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u);
+                    if (u < n_units) {
+                        stat_add(stats + kStatClosest, n_rays & 0xFFFFu);
+                        stat_add(stats + kStatShadow, n_rays >> 16);
+                        n_rays = 0;
+                        old_x0 = cur_x0;
+                        old_y0 = cur_y0;
+                        old_vw = cur_vw;
+                        old_nv = cur_nv;
+                        old_open = cur_open;
+                        gen ^= 1u;
+                        const uint32_t tile = u % n_tiles, chunk = u / n_tiles;
+                        cur_x0 = (tile % tiles_x) * 8u;
+                        cur_y0 = (tile / tiles_x) * 8u;
+                        cur_vw = min(8u, W - cur_x0);
+                        cur_nv = cur_vw * min(8u, H - cur_y0);  // pixels of an edge tile
+                        cur_s0 = s_begin_all + chunk * s_chunk;
+                        // u < n_units = tiles * ceil(s_count_all / s_chunk): the chunk starts inside the range
+                        cur_total = cur_nv * min(s_chunk, s_count_all - chunk * s_chunk);
+                        cur_next = 0;
+                        cur_open = true;
+                        n_paths_wave += cur_total;  // every item of a pool is traced
+                    } else {
+                        queue_empty = true;
+                    }
+                }
+            }
+            if (cur_open && cur_next < cur_total) {
+                const uint32_t k = cur_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+                cur_next = min(cur_total, cur_next + (uint32_t)__popcll(need));
+                if (!alive && k < cur_total) {
                     uint32_t px, py, smp;
-                    if (nv == 64u) {  // full tile (wave-uniform): no integer divisions
+                    if (cur_nv == 64u) {  // full tile (wave-uniform): no integer divisions
                         slot = k & 63u;
                         smp = k >> 6;
                         px = slot & 7u;
                         py = slot >> 3;
                     } else {
-                        slot = k % nv;
-                        smp = k / nv;
-                        px = slot % vw;
-                        py = slot / vw;
+                        slot = k % cur_nv;
+                        smp = k / cur_nv;
+                        px = slot % cur_vw;
+                        py = slot / cur_vw;
                     }
-                    generate_camera_path(S, (y0 + py) * W + x0 + px, s_begin + smp, p);
+                    generate_camera_path(S, (cur_y0 + py) * W + cur_x0 + px, cur_s0 + smp, p);
+                    lane_gen = gen;
                     alive = true;
                 }
             }
-            if (!__ballot(alive)) break;
-            if (alive) {
-                int tri;
-                double t;
-                ++n_rays;
-                trace<kScene, false>(S, lds, tq, p.o, p.d, 0.0, tri, t PROF_PASS);
-                alive = shade_bounce<kScene, 0x10000u>(S, lds, tq, p, tri, t, n_rays PROF_PASS) && p.depth < max_depth;
-                if (!alive) {
-                    atomicAdd(tile_acc + 3u * slot + 0u, (unsigned long long)radiance_to_fixed(p.rad.x));
-                    atomicAdd(tile_acc + 3u * slot + 1u, (unsigned long long)radiance_to_fixed(p.rad.y));
-                    atomicAdd(tile_acc + 3u * slot + 2u, (unsigned long long)radiance_to_fixed(p.rad.z));
-                }
+        }
+        if (!__ballot(alive)) {
+            if (queue_empty && !(cur_open && cur_next < cur_total)) break;  // reached by every wave: the counter only grows
+            continue;
+        }
+        if (alive) {
+            int tri;
+            double t;
+            ++n_rays;
+            trace<kScene, false>(S, lds, tq, p.o, p.d, 0.0, tri, t PROF_PASS);
+            alive = shade_bounce<kScene, 0x10000u>(S, lds, tq, p, tri, t, n_rays PROF_PASS) && p.depth < max_depth;
+            if (!alive) {
+                unsigned long long* acc = tile_acc + lane_gen * 192u + 3u * slot;
+                atomicAdd(acc + 0u, (unsigned long long)radiance_to_fixed(p.rad.x));
+                atomicAdd(acc + 1u, (unsigned long long)radiance_to_fixed(p.rad.y));
+                atomicAdd(acc + 2u, (unsigned long long)radiance_to_fixed(p.rad.z));
             }
         }
-#ifdef HPT_PROFILE
-        prof_add(prof, kProfDone, __builtin_readcyclecounter() - prof_start);
-        if (lane == 0 && S.prof)
-            for (int i = 0; i < 3 * kProfSections; ++i) atomicAdd(S.prof + i, prof.w[i]);
-#endif
-        n_paths_wave = lane == 0 ? total : 0u;  // every item of the pool was traced
-        unsigned long long* out = reinterpret_cast<unsigned long long*>(accum);
-        for (uint32_t j = lane; j < nv; j += wave_lanes) {
-            const unsigned long long pix = (unsigned long long)(y0 + j / vw) * W + x0 + j % vw;
-            atomicAdd(out + 3ull * pix + 0ull, tile_acc[3u * j + 0u]);
-            atomicAdd(out + 3ull * pix + 1ull, tile_acc[3u * j + 1u]);
-            atomicAdd(out + 3ull * pix + 2ull, tile_acc[3u * j + 2u]);
-        }
     }
+#ifdef HPT_PROFILE
+    prof_add(prof, kProfDone, __builtin_readcyclecounter() - prof_start);
+    if (lane == 0 && S.prof)
+        for (int i = 0; i < 3 * kProfSections; ++i) atomicAdd(S.prof + i, prof.w[i]);
+#endif
+    if (old_open) flush(tile_acc + (gen ^ 1u) * 192u, old_x0, old_y0, old_vw, old_nv);
+    if (cur_open) flush(tile_acc + gen * 192u, cur_x0, cur_y0, cur_vw, cur_nv);
     stat_add(stats + kStatClosest, n_rays & 0xFFFFu);
     stat_add(stats + kStatShadow, n_rays >> 16);
-    stat_add(stats + kStatPaths, n_paths_wave);
+    stat_add(stats + kStatPaths, lane == 0 ? n_paths_wave : 0u);
 }
 
 // ---- wavefront: 64-byte path records as four float4 planes -----------------
@@ -396,6 +442,7 @@ struct hpt_ctx {
     int64_t* d_accum = nullptr;
     size_t accum_elems = 0;
     unsigned long long* d_stats = nullptr;
+    uint32_t* d_unit_counter = nullptr;  // work-unit counter of the single-kernel mode
     unsigned long long* d_prof = nullptr;  // diagnostic builds only
     float* d_rgb = nullptr;  // staging for hpt_resolve
     // wavefront state
@@ -411,7 +458,7 @@ struct hpt_ctx {
     double kernel_ms = 0.0;
     uint32_t launches = 0;
     uint32_t spp_per_launch = 0;    // samples per pixel per single-kernel launch (HPT_SPP_PER_LAUNCH); 0 = about 2^28 paths
-    uint32_t spp_per_unit = 32;     // samples per pixel per wave work unit (HPT_SPP_PER_UNIT)
+    uint32_t spp_per_unit = 8;      // samples per pixel per wave work unit (HPT_SPP_PER_UNIT)
 };
 
 namespace {
@@ -605,6 +652,7 @@ int hpt_context_create(int device, hpt_ctx** out) {
     }
     hipError_t e = hipMalloc((void**)&ctx->d_stats, kNumStats * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(ctx->d_stats, 0, kNumStats * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_unit_counter, sizeof(uint32_t));
     if (e != hipSuccess) {
         delete ctx;
         return fail(HPT_ERR_HIP, "stats buffer: %s", hipGetErrorString(e));
@@ -626,6 +674,7 @@ int hpt_context_destroy(hpt_ctx* ctx) {
     free_scene(ctx);
     free_wavefront(ctx);
     (void)hipFree(ctx->d_stats);
+    (void)hipFree(ctx->d_unit_counter);
     delete ctx;
     return HPT_OK;
 }
@@ -848,26 +897,37 @@ int hpt_render(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sample
 
     if (mode == HPT_MODE_SINGLE_KERNEL) {
         const uint32_t waves_per_block = ((uint32_t)block + 63u) >> 6;
-        uint32_t lds_mega = lds + waves_per_block * 192u * 8u + (lds_bytes(S, block) - lds);  // + per-wave tile accumulators + queues
+        uint32_t lds_mega = lds + waves_per_block * 384u * 8u + (lds_bytes(S, block) - lds);  // + two tile accumulators per wave + queues
 #ifdef HPT_PROFILE
         lds_mega += waves_per_block * 3u * kProfSections * 8u;
 #endif
-        // per-lane ray counters are 16 bits wide: while its pool is not empty a wave's 64 lanes all
-        // advance, so a unit of c samples runs at most (c + 1) * max_depth loop iterations
-        const uint32_t chunk = std::max(1u, std::min(ctx->spp_per_unit, 65535u / (uint32_t)max_depth - 1u));
-        // at most 2^22 units per launch (the grid stays far below 2^31 lanes)
+        // per-lane ray counters are 16 bits wide and are emptied when a wave opens a unit; while a
+        // pool is not empty the wave's 64 lanes all advance, so between two openings a wave runs at
+        // most (c + 2) * max_depth loop iterations for units of c samples
+        const uint32_t cap = 65535u / (uint32_t)max_depth;
+        const uint32_t chunk = std::max(1u, std::min(ctx->spp_per_unit, cap > 2u ? cap - 2u : 1u));
+        // at most 2^22 units per launch
         const uint32_t max_chunks = std::max(1u, (1u << 22) / tiles);
         // launches of about 2^28 paths (256 spp at 1024x1024: ~0.25 s on the Cornell box) amortise the
         // launch's tail without running one kernel for many seconds on heavy scenes
         const uint32_t want = ctx->spp_per_launch ? ctx->spp_per_launch : std::max(1u, (1u << 22) / tiles);
         const uint32_t per_launch = std::max(1u, std::min(want, chunk * max_chunks));
+        // persistent waves: as many workgroups as are resident at once
+        int per_cu = 0;
+        HPT_DISPATCH_SCENE(S.variant, {
+            if (block <= 256) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_mega<kS, 256>, block, lds_mega));
+            else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_mega<kS, 1024>, block, lds_mega));
+        })
+        if (per_cu < 1) return fail(HPT_ERR_INVALID_ARGUMENT, "a workgroup of %d lanes with %u bytes of LDS does not fit a compute unit", block, lds_mega);
+        const uint32_t resident = (uint32_t)per_cu * (uint32_t)ctx->num_cus;
         for (uint32_t s = sample_begin; s < sample_begin + sample_count;) {
             const uint32_t n = (sample_begin + sample_count - s > per_launch) ? per_launch : sample_begin + sample_count - s;
             const uint32_t units = tiles * ((n + chunk - 1u) / chunk);
-            const uint32_t blocks = (units + waves_per_block - 1u) / waves_per_block;
+            const uint32_t blocks = std::min(resident, (units + waves_per_block - 1u) / waves_per_block);
+            HIP_TRY(hipMemsetAsync(ctx->d_unit_counter, 0, sizeof(uint32_t), stream));
             HPT_DISPATCH_SCENE(S.variant, {
-                if (block <= 256) hipLaunchKernelGGL((k_render_mega<kS, 256>), dim3(blocks), dim3(block), lds_mega, stream, S, max_depth, s, n, chunk, units, accum, ctx->d_stats);
-                else hipLaunchKernelGGL((k_render_mega<kS, 1024>), dim3(blocks), dim3(block), lds_mega, stream, S, max_depth, s, n, chunk, units, accum, ctx->d_stats);
+                if (block <= 256) hipLaunchKernelGGL((k_render_mega<kS, 256>), dim3(blocks), dim3(block), lds_mega, stream, S, max_depth, s, n, chunk, units, accum, ctx->d_stats, ctx->d_unit_counter);
+                else hipLaunchKernelGGL((k_render_mega<kS, 1024>), dim3(blocks), dim3(block), lds_mega, stream, S, max_depth, s, n, chunk, units, accum, ctx->d_stats, ctx->d_unit_counter);
             })
             HIP_TRY(hipGetLastError());
             ++launches;

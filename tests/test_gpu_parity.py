@@ -154,8 +154,8 @@ def test_block_sizes_give_identical_images(hp, oracle, gpu_ctx, block, mode):
 
 
 def test_sample_chunks_and_spare_waves(hp, oracle, gpu_ctx):
-    """mode 1 splits a launch into (tile, chunk of 32 samples) units: 70 samples = chunks of 32, 32, 6;
-    15 tiles x 3 chunks = 45 units on workgroups of 2 waves leaves one wave without a unit."""
+    """mode 1 splits a launch into (tile, chunk of 8 samples) units: 70 samples = 8 chunks of 8 and one of 6;
+    waves draw units from a counter and hold paths of two units at a time."""
     w, h, depth, spp = 40, 24, 4, 70
     sc = hp.Scene.CreateBuiltinScene(hp.Scene.CornellBox, depth, w, h)
     osc = oracle.cornell(w, h)
