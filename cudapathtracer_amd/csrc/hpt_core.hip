@@ -34,6 +34,8 @@ using namespace hpt;
 namespace {
 
 constexpr uint32_t kLdsLimit = 32u * 1024u;
+constexpr uint32_t kLdsLimitTiny = 40u * 1024u;  // eight node copies of a 64-triangle scene (127 nodes) + its triangles
+constexpr uint32_t kMaxLdsPerBlock = 160u * 1024u;  // LDS of a gfx950 compute unit; one workgroup may use all of it
 constexpr uint32_t kMaxStackDepth = 40;  // per-lane stack entries (4 B each in LDS); median-split trees need ~log2(triangles)
 constexpr int kStatClosest = 0, kStatShadow = 1, kStatPaths = 2, kNumStats = 4;
 
@@ -419,8 +421,7 @@ __global__ void k_resolve(const int64_t* __restrict__ accum, size_t n, double de
     case kSceneTiny32: { constexpr int kS = kSceneTiny32; CALL; } break;          \
     case kSceneTiny64: { constexpr int kS = kSceneTiny64; CALL; } break;          \
     case kScenePair: { constexpr int kS = kScenePair; CALL; } break;              \
-    case kScenePairLds: { constexpr int kS = kScenePairLds; CALL; } break;        \
-    default: { constexpr int kS = kSceneSweep; CALL; } break;                     \
+    default: { constexpr int kS = kScenePairLds; CALL; } break;                   \
     }
 
 // ------------------------------------------------------------------ context --
@@ -823,27 +824,32 @@ int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* sc) {
         S.root_lo[c] = sc->nodes[c];
         S.root_hi[c] = sc->nodes[4 + c];
     }
-    const uint64_t f4 = 2ull * nn + 4ull * nt;        // threaded nodes + triangles
-    const uint64_t f4_pair = 4ull * num_pairs + 4ull * nt;  // two-child records + triangles (about the same)
+    const uint64_t f4 = 2ull * nn + 4ull * nt;             // threaded nodes + triangles
+    const uint64_t f4_tiny = 16ull * nn + 4ull * nt;       // eight octant copies of the nodes + triangles
+    const uint64_t f4_pair = 4ull * num_pairs + 4ull * nt;  // two-child records + triangles
     const bool fits = f4 * 16ull <= kLdsLimit, fits_pair = f4_pair * 16ull <= kLdsLimit;
+    const bool fits_tiny = f4_tiny * 16ull <= kLdsLimitTiny;
     const bool pair_ok = num_pairs > 0 && stack_depth <= kMaxStackDepth;
-    // (the wave-uniform sweep, kSceneSweep, measured slower than the per-lane walk: 17.1 vs 19.1 Grays/s on
-    // incoherent rays; it stays selectable with HPT_TRACE_VARIANT=4 for experiments)
-    if (fits && nt <= 32) S.variant = kSceneTiny32;
-    else if (fits && nt <= 64) S.variant = kSceneTiny64;
+    if (fits_tiny && nt <= 32) S.variant = kSceneTiny32;
+    else if (fits_tiny && nt <= 64) S.variant = kSceneTiny64;
     else if (pair_ok) S.variant = fits_pair ? kScenePairLds : kScenePair;
     else S.variant = fits ? kSceneLds : kSceneGlobal;
     if (const char* e = getenv("HPT_TRACE_VARIANT")) {  // experiments: force another variant
         const int v = atoi(e);
         if (v == kSceneGlobal) S.variant = kSceneGlobal;
         else if (v == kSceneLds && fits) S.variant = kSceneLds;
-        else if (v == kSceneTiny64 && fits && nt <= 64) S.variant = kSceneTiny64;
-        else if (v == kSceneTiny32 && fits && nt <= 32) S.variant = kSceneTiny32;
-        else if (v == kSceneSweep && fits && nt <= 32 && nn <= kSweepMaxNodes) S.variant = kSceneSweep;
+        else if (v == kSceneTiny64 && fits_tiny && nt <= 64) S.variant = kSceneTiny64;
+        else if (v == kSceneTiny32 && fits_tiny && nt <= 32) S.variant = kSceneTiny32;
         else if (v == kScenePair && pair_ok) S.variant = kScenePair;
         else if (v == kScenePairLds && pair_ok && fits_pair) S.variant = kScenePairLds;
     }
-    S.lds_float4s = (S.variant == kSceneGlobal || S.variant == kScenePair) ? 0u : (S.variant == kScenePairLds ? (uint32_t)f4_pair : (uint32_t)f4);
+    switch (S.variant) {
+    case kSceneLds: S.lds_float4s = (uint32_t)f4; break;
+    case kSceneTiny32:
+    case kSceneTiny64: S.lds_float4s = (uint32_t)f4_tiny; break;
+    case kScenePairLds: S.lds_float4s = (uint32_t)f4_pair; break;
+    default: S.lds_float4s = 0u; break;
+    }
     ctx->has_scene = true;
     return HPT_OK;
 }
@@ -913,10 +919,17 @@ int hpt_render(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sample
         const uint32_t want = ctx->spp_per_launch ? ctx->spp_per_launch : std::max(1u, (1u << 22) / tiles);
         const uint32_t per_launch = std::max(1u, std::min(want, chunk * max_chunks));
         // persistent waves: as many workgroups as are resident at once
+        if (lds_mega > kMaxLdsPerBlock)
+            return fail(HPT_ERR_INVALID_ARGUMENT, "a workgroup of %d lanes needs %u bytes of LDS for this scene (limit %u): use a smaller block", block, lds_mega, kMaxLdsPerBlock);
         int per_cu = 0;
         HPT_DISPATCH_SCENE(S.variant, {
-            if (block <= 256) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_mega<kS, 256>, block, lds_mega));
-            else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_mega<kS, 1024>, block, lds_mega));
+            if (block <= 256) {
+                if (lds_mega > 48u * 1024u) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render_mega<kS, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mega));
+                HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_mega<kS, 256>, block, lds_mega));
+            } else {
+                if (lds_mega > 48u * 1024u) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render_mega<kS, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mega));
+                HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_mega<kS, 1024>, block, lds_mega));
+            }
         })
         if (per_cu < 1) return fail(HPT_ERR_INVALID_ARGUMENT, "a workgroup of %d lanes with %u bytes of LDS does not fit a compute unit", block, lds_mega);
         const uint32_t resident = (uint32_t)per_cu * (uint32_t)ctx->num_cus;

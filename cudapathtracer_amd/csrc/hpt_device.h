@@ -245,13 +245,7 @@ enum {
     kScenePairLds = 6, // with a per-lane stack in LDS; one dependent fetch per two box tests.
                        // Records read through L1/L2 (5) or staged in LDS (6).  Same box tests,
                        // same leaves reached as the threaded walk, in a different order.
-    kSceneSweep = 4    // <= 32 triangles and <= kSweepMaxNodes nodes: as Tiny32, but the box phase
-                       // is a wave-uniform sweep over ALL nodes in pre-order: the node record is
-                       // fetched once per wave with scalar loads (operands in SGPRs, no LDS access,
-                       // no dependent address), each lane takes part at a node only if its own
-                       // walk would be there.  Same tests per lane, no load latency on the walk.
 };
-constexpr uint32_t kSweepMaxNodes = 96;
 
 template <int kScene>
 HD void stage_scene(const DevScene& S, float4* lds) {
@@ -262,18 +256,35 @@ HD void stage_scene(const DevScene& S, float4* lds) {
         for (uint32_t i = threadIdx.x; i < np; i += blockDim.x) lds[i] = S.pairs[i];
         for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) lds[np + i] = S.tris[i];
         __syncthreads();
-    } else {
-        constexpr bool kLeafBits = (kScene == kSceneTiny32 || kScene == kSceneSweep);
+    } else if constexpr (kScene == kSceneLds) {
         const uint32_t nn = 2u * S.num_nodes, nt = 4u * S.num_tris;
-        for (uint32_t i = threadIdx.x; i < nn; i += blockDim.x) {
-            float4 v = S.nodes[i];
-            if (kLeafBits && (i & 1u)) {  // pMax half: triangle index -> its bit in the pending mask (0 = interior)
-                const int tri = __float_as_int(v.w);
-                v.w = __uint_as_float(tri >= 0 ? 1u << tri : 0u);
-            }
-            lds[i] = v;
-        }
+        for (uint32_t i = threadIdx.x; i < nn; i += blockDim.x) lds[i] = S.nodes[i];
         for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) lds[nn + i] = S.tris[i];
+        __syncthreads();
+    } else {
+        // Marking variants: EIGHT copies of the node array, one per sign octant of the ray
+        // direction (bit 0/1/2 = x/y/z negative).  Copy k holds per node
+        //   (near.xyz, byte offset of the miss target inside copy k) (far.xyz, leaf word)
+        // with near/far = the slab planes a ray of that octant enters/leaves through
+        // (Bounds3::IntersectP's dirIsNeg selection, common/Bounds3.hpp:100-116, done once at
+        // staging instead of per test).  Leaf word: the triangle's bit in the pending mask
+        // (32-triangle variants; 0 = interior) or the triangle index / -1 (64).
+        constexpr bool kLeafBits = (kScene == kSceneTiny32);
+        const uint32_t nn = S.num_nodes, nt = 4u * S.num_tris;
+        for (uint32_t i = threadIdx.x; i < 8u * nn; i += blockDim.x) {
+            const uint32_t k = i / nn, n = i - k * nn;
+            const float4 lo = S.nodes[2u * n], hi = S.nodes[2u * n + 1u];
+            const bool sx = k & 1u, sy = k & 2u, sz = k & 4u;
+            float leaf = hi.w;
+            if (kLeafBits) {
+                const int tri = __float_as_int(hi.w);
+                leaf = __uint_as_float(tri >= 0 ? 1u << tri : 0u);
+            }
+            const uint32_t miss_off = (k * nn + (uint32_t)__float_as_int(lo.w)) * 32u;
+            lds[2u * i] = make_float4(sx ? hi.x : lo.x, sy ? hi.y : lo.y, sz ? hi.z : lo.z, __uint_as_float(miss_off));
+            lds[2u * i + 1u] = make_float4(sx ? lo.x : hi.x, sy ? lo.y : hi.y, sz ? lo.z : hi.z, leaf);
+        }
+        for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) lds[16u * nn + i] = S.tris[i];
         __syncthreads();
     }
 }
@@ -360,9 +371,12 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
     } else if constexpr (kScene == kScenePair) {
         N = S.pairs;
         T = S.tris;
-    } else if constexpr (kScene != kSceneGlobal) {
+    } else if constexpr (kScene == kSceneLds) {
         N = lds;
         T = lds + 2u * S.num_nodes;
+    } else if constexpr (kScene != kSceneGlobal) {
+        N = lds;  // eight octant copies of the nodes, see stage_scene
+        T = lds + 16u * S.num_nodes;
     } else {
         N = S.nodes;
         T = S.tris;
@@ -374,53 +388,39 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
     double best_t = (double)kInfinity;
     int node = 0;
     const int end = (int)S.num_nodes;
-    if constexpr (kScene == kSceneTiny32 || kScene == kSceneTiny64 || kScene == kSceneSweep) {
+    if constexpr (kScene == kSceneTiny32 || kScene == kSceneTiny64) {
         constexpr bool kMask32 = (kScene != kSceneTiny64);
         using mask_t = typename std::conditional<kMask32, uint32_t, unsigned long long>::type;
         mask_t pending = 0;
         const float kInf = __builtin_inff();
         PROF_T0();
         const bool finite = fabsf(inv.x) < kInf && fabsf(inv.y) < kInf && fabsf(inv.z) < kInf;
-        if constexpr (kScene == kSceneSweep) {
-            int cur = finite ? 0 : end;  // lanes with a zero direction component take the exact walk below
-            // constant address space: the table is immutable while kernels run, and a
-            // wave-uniform index then compiles to scalar loads (node operands in SGPRs)
-            typedef float raw_f4 __attribute__((ext_vector_type(4)));
-            typedef __attribute__((address_space(4))) const raw_f4 const_f4;
-            const const_f4* G = (const const_f4*)(uintptr_t)S.nodes;
-#pragma unroll 4
-            for (int n = 0; n < end; ++n) {
-                PROF_ITER(kShadow ? kProfBoxS : kProfBoxC);
-                const raw_f4 rlo = G[2 * n], rhi = G[2 * n + 1];  // wave-uniform address
-                const float4 lo = make_float4(rlo.x, rlo.y, rlo.z, rlo.w), hi = make_float4(rhi.x, rhi.y, rhi.z, rhi.w);
-                const int tri = __float_as_int(hi.w);
-                const uint32_t bit = tri >= 0 ? 1u << tri : 0u;
-                const int miss = __float_as_int(lo.w);
-                // no per-lane branch: every lane evaluates the test, only lanes whose own
-                // walk is at this node use the result
-                const bool at = cur == n;
-                const bool hit = box_hit_finite(lo, hi, o, inv);
-                pending |= (at && hit) ? bit : 0u;
-                cur = at ? (hit ? n + 1 : miss) : cur;
-            }
-            node = finite ? end : 0;
-        }
+        const char* const nbase = reinterpret_cast<const char*>(N);
+        const uint32_t copy_bytes = S.num_nodes * 32u;
         if (finite) {
-            while (node < end) {
+            // walk the copy of this ray's octant; `at` is the node's byte offset, links are byte offsets too
+            const uint32_t oct = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
+            uint32_t at = oct * copy_bytes;
+            const uint32_t stop = at + copy_bytes;
+            while (at < stop) {
                 PROF_ITER(kShadow ? kProfBoxS : kProfBoxC);
-                const float4 lo = N[2 * node], hi = N[2 * node + 1];
-                const bool hit = box_hit_finite(lo, hi, o, inv);
+                const float4 nr = *reinterpret_cast<const float4*>(nbase + at), fr = *reinterpret_cast<const float4*>(nbase + at + 16);
+                // Bounds3::IntersectP with the planes already ordered; equals box_hit for finite reciprocals
+                const float tnear = fmaxf(fmaxf((nr.x - o.x) * inv.x, (nr.y - o.y) * inv.y), (nr.z - o.z) * inv.z);
+                const float tfar = fminf(fminf((fr.x - o.x) * inv.x, (fr.y - o.y) * inv.y), (fr.z - o.z) * inv.z);
+                const bool hit = tnear <= tfar;
                 if constexpr (kMask32) {
-                    pending |= hit ? __float_as_uint(hi.w) : 0u;  // staged as a leaf bit
+                    pending |= hit ? __float_as_uint(fr.w) : 0u;  // staged as a leaf bit
                 } else {
-                    const int tri = __float_as_int(hi.w);
+                    const int tri = __float_as_int(fr.w);
                     if (hit && tri >= 0) pending |= (mask_t)1 << tri;
                 }
-                node = hit ? node + 1 : __float_as_int(lo.w);
+                at = hit ? at + 32u : __float_as_uint(nr.w);
             }
-        } else {  // a direction component is 0 (or denormal): the reference's NaN-aware sequence
-            while (node < end) {
-                const float4 lo = N[2 * node], hi = N[2 * node + 1];
+        } else {  // a direction component is 0 (or denormal): the reference's NaN-aware sequence, on copy 0 (near = pMin)
+            uint32_t at = 0;
+            while (at < copy_bytes) {
+                const float4 lo = *reinterpret_cast<const float4*>(nbase + at), hi = *reinterpret_cast<const float4*>(nbase + at + 16);
                 const bool hit = box_hit(lo, hi, o, inv, nx, ny, nz);
                 if constexpr (kMask32) {
                     pending |= hit ? __float_as_uint(hi.w) : 0u;
@@ -428,7 +428,7 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
                     const int tri = __float_as_int(hi.w);
                     if (hit && tri >= 0) pending |= (mask_t)1 << tri;
                 }
-                node = hit ? node + 1 : __float_as_int(lo.w);
+                at = hit ? at + 32u : __float_as_uint(lo.w);
             }
         }
         PROF_T1(kShadow ? kProfBoxS : kProfBoxC);

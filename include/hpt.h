@@ -111,7 +111,7 @@ typedef struct {
     double kernel_ms;         /* HIP-event time of hpt_render's kernels, summed since the last hpt_stats_reset */
     uint32_t launches;        /* kernel launches of hpt_render, summed since the last hpt_stats_reset        */
     uint32_t variant;         /* traversal variant chosen for the uploaded scene: 0 threaded walk through L1/L2,
-                                 1 the same from LDS, 2/3 LDS with a 32-/64-bit leaf mask, 4 wave-uniform sweep,
+                                 1 the same from LDS, 2/3 LDS with a 32-/64-bit leaf mask,
                                  5 two-child records + stack through L1/L2, 6 the same from LDS */
 } hpt_stats;
 
