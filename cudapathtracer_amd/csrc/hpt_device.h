@@ -247,6 +247,16 @@ enum {
                        // same leaves reached as the threaded walk, in a different order.
 };
 
+// LDS byte address of a pointer into shared memory (the low half of its flat address), and a
+// 16-byte read at such an address: the address register goes into ds_read_b128 as it is
+typedef float raw_float4 __attribute__((ext_vector_type(4)));
+typedef const raw_float4 __attribute__((address_space(3))) lds_float4;
+HD uint32_t lds_address(const void* p) { return (uint32_t)reinterpret_cast<uintptr_t>(p); }
+HD float4 lds_read(uint32_t at) {
+    const raw_float4 v = *reinterpret_cast<lds_float4*>(static_cast<uintptr_t>(at));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 template <int kScene>
 HD void stage_scene(const DevScene& S, float4* lds) {
     if constexpr (kScene == kSceneGlobal || kScene == kScenePair) {
@@ -264,7 +274,7 @@ HD void stage_scene(const DevScene& S, float4* lds) {
     } else {
         // Marking variants: EIGHT copies of the node array, one per sign octant of the ray
         // direction (bit 0/1/2 = x/y/z negative).  Copy k holds per node
-        //   (near.xyz, byte offset of the miss target inside copy k) (far.xyz, leaf word)
+        //   (near.xyz, LDS address of the miss target inside copy k) (far.xyz, leaf word)
         // with near/far = the slab planes a ray of that octant enters/leaves through
         // (Bounds3::IntersectP's dirIsNeg selection, common/Bounds3.hpp:100-116, done once at
         // staging instead of per test).  Leaf word: the triangle's bit in the pending mask
@@ -280,8 +290,8 @@ HD void stage_scene(const DevScene& S, float4* lds) {
                 const int tri = __float_as_int(hi.w);
                 leaf = __uint_as_float(tri >= 0 ? 1u << tri : 0u);
             }
-            const uint32_t miss_off = (k * nn + (uint32_t)__float_as_int(lo.w)) * 32u;
-            lds[2u * i] = make_float4(sx ? hi.x : lo.x, sy ? hi.y : lo.y, sz ? hi.z : lo.z, __uint_as_float(miss_off));
+            const uint32_t miss_at = lds_address(lds) + (k * nn + (uint32_t)__float_as_int(lo.w)) * 32u;
+            lds[2u * i] = make_float4(sx ? hi.x : lo.x, sy ? hi.y : lo.y, sz ? hi.z : lo.z, __uint_as_float(miss_at));
             lds[2u * i + 1u] = make_float4(sx ? lo.x : hi.x, sy ? lo.y : hi.y, sz ? lo.z : hi.z, leaf);
         }
         for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) lds[16u * nn + i] = S.tris[i];
@@ -395,16 +405,15 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
         const float kInf = __builtin_inff();
         PROF_T0();
         const bool finite = fabsf(inv.x) < kInf && fabsf(inv.y) < kInf && fabsf(inv.z) < kInf;
-        const char* const nbase = reinterpret_cast<const char*>(N);
-        const uint32_t copy_bytes = S.num_nodes * 32u;
+        const uint32_t nbase = lds_address(N), copy_bytes = S.num_nodes * 32u;
         if (finite) {
-            // walk the copy of this ray's octant; `at` is the node's byte offset, links are byte offsets too
+            // walk the copy of this ray's octant; `at` is the node's LDS address, links are addresses too
             const uint32_t oct = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
-            uint32_t at = oct * copy_bytes;
+            uint32_t at = nbase + oct * copy_bytes;
             const uint32_t stop = at + copy_bytes;
             while (at < stop) {
                 PROF_ITER(kShadow ? kProfBoxS : kProfBoxC);
-                const float4 nr = *reinterpret_cast<const float4*>(nbase + at), fr = *reinterpret_cast<const float4*>(nbase + at + 16);
+                const float4 nr = lds_read(at), fr = lds_read(at + 16u);
                 // Bounds3::IntersectP with the planes already ordered; equals box_hit for finite reciprocals
                 const float tnear = fmaxf(fmaxf((nr.x - o.x) * inv.x, (nr.y - o.y) * inv.y), (nr.z - o.z) * inv.z);
                 const float tfar = fminf(fminf((fr.x - o.x) * inv.x, (fr.y - o.y) * inv.y), (fr.z - o.z) * inv.z);
@@ -418,9 +427,9 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
                 at = hit ? at + 32u : __float_as_uint(nr.w);
             }
         } else {  // a direction component is 0 (or denormal): the reference's NaN-aware sequence, on copy 0 (near = pMin)
-            uint32_t at = 0;
-            while (at < copy_bytes) {
-                const float4 lo = *reinterpret_cast<const float4*>(nbase + at), hi = *reinterpret_cast<const float4*>(nbase + at + 16);
+            uint32_t at = nbase;
+            while (at < nbase + copy_bytes) {
+                const float4 lo = lds_read(at), hi = lds_read(at + 16u);
                 const bool hit = box_hit(lo, hi, o, inv, nx, ny, nz);
                 if constexpr (kMask32) {
                     pending |= hit ? __float_as_uint(hi.w) : 0u;
