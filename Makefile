@@ -13,7 +13,11 @@ CXX      ?= g++
 ARCH     ?= gfx950
 # -ffp-contract=off: the device arithmetic is specified operation by operation
 # (bit-exact against a CPU evaluation); contraction into FMA would change results.
-HIPFLAGS ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -ffp-contract=off -fno-fast-math \
+# -fno-slp-vectorize: the SLP vectoriser pairs adjacent float adds/multiplies into packed-f32
+# instructions (v_pk_add_f32 / v_pk_mul_f32) plus register shuffles; in these instruction mixes
+# that measured slower on gfx950 than the scalar forms (tools/micro/pk_mix.hip; 7 % on the
+# single-kernel render) and needs more registers.
+HIPFLAGS ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize \
             -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-rdc -Wall -Wno-unused-function
 CXXFLAGS ?= -O2 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall
 
@@ -29,7 +33,7 @@ HOST_HDRS := $(wildcard $(HOST)/*.hpp) include/hpt.h include/hpt_host.h
 all: hpt host oracle
 
 hpt: $(PKG)/libhpt.so
-$(PKG)/libhpt.so: $(CSRC)/hpt_core.hip $(CSRC)/hpt_device.h include/hpt.h
+$(PKG)/libhpt.so: $(CSRC)/hpt_core.hip $(CSRC)/hpt_device.h include/hpt.h Makefile
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/hpt_core.hip
 
 host: $(PKG)/libhpt_host.so build/gpu_path_tracer
