@@ -137,7 +137,12 @@ k_render_mega(DevScene S, int max_depth, uint32_t s_begin_all, uint32_t s_count_
     unsigned long long* tile_acc = reinterpret_cast<unsigned long long*>(lds + S.lds_float4s) + wave * 384u;
     for (uint32_t i = lane; i < 384u; i += wave_lanes) tile_acc[i] = 0ull;
     // triangle queues / stacks (variants that use them) lie behind all waves' accumulators
-    const TriQueue tq = make_tri_queue(reinterpret_cast<uint32_t*>(lds + S.lds_float4s) + waves_per_block * 768u);
+#ifdef HPT_PROFILE
+    const uint32_t prof_words = waves_per_block * 3u * kProfSections * 2u;  // per-wave section counters, behind the accumulators
+#else
+    const uint32_t prof_words = 0u;
+#endif
+    const TriQueue tq = make_tri_queue(reinterpret_cast<uint32_t*>(lds + S.lds_float4s) + waves_per_block * 768u + prof_words);
     stage_scene<kScene>(S, lds);
 
     const uint32_t W = (uint32_t)S.width, H = (uint32_t)S.height;
@@ -168,7 +173,7 @@ k_render_mega(DevScene S, int max_depth, uint32_t s_begin_all, uint32_t s_count_
     Path p;
 #ifdef HPT_PROFILE
     ProfAcc prof;
-    prof.w = tile_acc + 384u * (waves_per_block - wave) + ((kTriQueue + S.stack_depth) * blockDim.x + 1u) / 2u + wave * 3u * kProfSections;  // behind accumulators and queues
+    prof.w = tile_acc + 384u * (waves_per_block - wave) + wave * 3u * kProfSections;
     for (uint32_t i = lane; i < 3u * kProfSections; i += wave_lanes) prof.w[i] = 0ull;
     const unsigned long long prof_start = __builtin_readcyclecounter();
 #endif

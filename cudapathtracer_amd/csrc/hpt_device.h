@@ -329,9 +329,13 @@ HD bool box_hit_finite(const float4 lo, const float4 hi, f3 o, f3 inv) {
 
 // Triangle::getIntersection (common/Triangle.hpp:164-198): back-face cull,
 // float cross/dot products, double det, 1/det, u, v, t.
+// kCulled: the caller has already dropped back-facing triangles.
+template <bool kCulled = false>
 HD bool tri_hit(const float4* __restrict__ T, int tri, f3 o, f3 d, double& t_out) {
-    const f3 n = xyz(T[4 * tri + 3]);
-    if (dot(d, n) > 0) return false;
+    if constexpr (!kCulled) {
+        const f3 n = xyz(T[4 * tri + 3]);
+        if (dot(d, n) > 0) return false;
+    }
     const f3 v0 = xyz(T[4 * tri]), e1 = xyz(T[4 * tri + 1]), e2 = xyz(T[4 * tri + 2]);
     const f3 pvec = cross(d, e2);
     const float detf = dot(e1, pvec);
@@ -445,15 +449,16 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
         // that the expensive rounds below are only as many as the busiest lane needs
         for (mask_t m = pending; m;) {
             const int tri = kMask32 ? __ffs((int)m) - 1 : __ffsll((long long)m) - 1;
-            m &= m - 1;
-            if (dot(d, xyz(T[4 * tri + 3])) > 0) pending &= ~((mask_t)1 << tri);
+            const mask_t rest = m & (m - 1);
+            if (dot(d, xyz(T[4 * tri + 3])) > 0) pending ^= m ^ rest;  // m ^ rest = the bit just examined
+            m = rest;
         }
         while (pending) {
             PROF_ITER(kShadow ? kProfTriS : kProfTriC);
             const int tri = kMask32 ? __ffs((int)pending) - 1 : __ffsll((long long)pending) - 1;
             pending &= pending - 1;
             double t;
-            if (tri_hit(T, tri, o, d, t)) {
+            if (tri_hit<true>(T, tri, o, d, t)) {
                 if constexpr (kShadow) {
                     if (t < limit) {
                         best = tri;
