@@ -464,7 +464,7 @@ struct hpt_ctx {
     double kernel_ms = 0.0;
     uint32_t launches = 0;
     uint32_t spp_per_launch = 0;    // samples per pixel per single-kernel launch (HPT_SPP_PER_LAUNCH); 0 = about 2^28 paths
-    uint32_t spp_per_unit = 8;      // samples per pixel per wave work unit (HPT_SPP_PER_UNIT)
+    uint32_t spp_per_unit = 16;     // samples per pixel per wave work unit (HPT_SPP_PER_UNIT)
 };
 
 namespace {
