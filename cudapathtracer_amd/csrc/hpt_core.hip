@@ -6,7 +6,7 @@
 //                      path ends starts its next sample at once, so the wave
 //                      stays full although path lengths differ from 1 to
 //                      max_depth bounces
-//   k_wf_generate / k_wf_extend / k_wf_shade
+//   k_wf_generate / k_wf_bounce
 //                      mode 2: wavefront; path state lives in 64-byte SoA
 //                      records, survivors are compacted with a wave ballot +
 //                      prefix count and one atomic per wave, the live count
@@ -329,55 +329,33 @@ __global__ void k_wf_generate(DevScene S, uint32_t s_begin, uint64_t first, uint
     stat_add(stats + kStatPaths, made);
 }
 
-// ComputeIntersections (gpu_path_tracer/CudaPathTrace.cu:64-78)
+// One bounce of every live path: ComputeIntersections + IntegratePathSegment + the two thrust
+// compactions + FinalGather (gpu_path_tracer/CudaPathTrace.cu:64-111, :149-157) in one pass.
+// A lane loads a path record, finds its closest hit, shades it (light sample with the inline
+// any-hit shadow query, BSDF sample) and then either appends the survivor to the other queue or
+// adds the finished path's radiance to its pixel (int64 atomics).  Survivors are compacted with
+// __ballot + prefix popcount and one atomicAdd per wave.  The live count stays on the device:
+// the kernel is grid-stride over *live_in, workgroups beyond it exit before staging the scene,
+// the host never waits between bounces.
 template <int kScene>
 __global__ void __launch_bounds__(256)
-k_wf_extend(DevScene S, WfQueue q, const uint32_t* __restrict__ live_count, int2* __restrict__ hits,
-            unsigned long long* __restrict__ stats) {
-    extern __shared__ float4 lds[];
-    const uint32_t count = *live_count;
-    if (blockIdx.x * blockDim.x >= count) return;  // late bounces: most workgroups have no path left
-    stage_scene<kScene>(S, lds);
-    const uint32_t stride = gridDim.x * blockDim.x;
-    const TriQueue tq = make_tri_queue(reinterpret_cast<uint32_t*>(lds + S.lds_float4s));
-    uint32_t n_closest = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
-        const float4 a = q.a[i], b = q.b[i];
-        int tri = -1;
-        double t = (double)kInfinity;
-        if (__float_as_uint(b.w) != 0xFFFFFFFFu) {
-            ++n_closest;
-#ifdef HPT_PROFILE
-            __shared__ unsigned long long prof_dummy[3 * kProfSections];
-            ProfAcc prof;
-            prof.w = prof_dummy;
-#endif
-            trace<kScene, false>(S, lds, tq, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), 0.0, tri, t PROF_PASS);
-        }
-        hits[i] = make_int2(tri, __float_as_int((float)t));
-    }
-    stat_add(stats + kStatClosest, n_closest);
-}
-
-// IntegratePathSegment + the two thrust compactions + FinalGather
-// (gpu_path_tracer/CudaPathTrace.cu:80-111, :149-157) in one pass: shade,
-// then either append the survivor to the next queue or add the finished
-// path's radiance to its pixel.
-template <int kScene>
-__global__ void __launch_bounds__(256)
-k_wf_shade(DevScene S, int max_depth, WfQueue q_in, const int2* __restrict__ hits, const uint32_t* __restrict__ live_in,
-           WfQueue q_out, uint32_t* __restrict__ live_out, int64_t* __restrict__ accum,
-           unsigned long long* __restrict__ stats) {
+k_wf_bounce(DevScene S, int max_depth, WfQueue q_in, const uint32_t* __restrict__ live_in, WfQueue q_out,
+            uint32_t* __restrict__ live_out, int64_t* __restrict__ accum, unsigned long long* __restrict__ stats) {
     extern __shared__ float4 lds[];
     const uint32_t count = *live_in;
-    if (blockIdx.x * blockDim.x >= count) return;
+    if (blockIdx.x * blockDim.x >= count) return;  // late bounces: most workgroups have no path left
     stage_scene<kScene>(S, lds);
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t lane = threadIdx.x & 63u;
     const TriQueue tq = make_tri_queue(reinterpret_cast<uint32_t*>(lds + S.lds_float4s));
-    uint32_t n_shadow = 0;
-    // all lanes of a wave run the same number of iterations so that the
-    // ballot below always sees the whole wave
+    uint32_t n_closest = 0, n_shadow = 0;
+#ifdef HPT_PROFILE
+    __shared__ unsigned long long prof_dummy[3 * kProfSections];
+    ProfAcc prof;
+    prof.w = prof_dummy;
+#endif
+    // all lanes of a wave run the same number of iterations so that the ballot below always
+    // sees the whole wave
     const uint32_t wave_first = (blockIdx.x * blockDim.x + threadIdx.x) - lane;
     for (uint32_t base = wave_first; base < count; base += stride) {
         const uint32_t i = base + lane;
@@ -385,16 +363,12 @@ k_wf_shade(DevScene S, int max_depth, WfQueue q_in, const int2* __restrict__ hit
         Path p;
         if (i < count) {
             wf_load(q_in, i, p);
-            if (p.pixel != 0xFFFFFFFFu) {
-                const int2 h = hits[i];
-                // the float conversion of t happens here in the single-kernel
-                // path as well (Ray::operator() narrows t, Ray.hpp:27)
-#ifdef HPT_PROFILE
-                __shared__ unsigned long long prof_dummy[3 * kProfSections];
-                ProfAcc prof;
-                prof.w = prof_dummy;
-#endif
-                keep = shade_bounce<kScene>(S, lds, tq, p, h.x, (double)__int_as_float(h.y), n_shadow PROF_PASS) && p.depth < max_depth;
+            if (p.pixel != 0xFFFFFFFFu) {  // not the dead record of a partial edge tile
+                int tri;
+                double t;
+                ++n_closest;
+                trace<kScene, false>(S, lds, tq, p.o, p.d, 0.0, tri, t PROF_PASS);
+                keep = shade_bounce<kScene>(S, lds, tq, p, tri, t, n_shadow PROF_PASS) && p.depth < max_depth;
                 if (!keep) accumulate_pixel(accum, p.pixel, p.rad);
             }
         }
@@ -407,6 +381,7 @@ k_wf_shade(DevScene S, int max_depth, WfQueue q_in, const int2* __restrict__ hit
             if (keep) wf_store(q_out, slot + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)), p);
         }
     }
+    stat_add(stats + kStatClosest, n_closest);
     stat_add(stats + kStatShadow, n_shadow);
 }
 
@@ -452,10 +427,9 @@ struct hpt_ctx {
     unsigned long long* d_prof = nullptr;  // diagnostic builds only
     float* d_rgb = nullptr;  // staging for hpt_resolve
     // wavefront state
-    uint64_t wf_capacity = 1ull << 22;
+    uint64_t wf_capacity = 1ull << 24;  // paths per wavefront batch (2 queues x 64 B each: 2 GiB)
     uint64_t wf_allocated = 0;
     float4* d_wf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    int2* d_hits = nullptr;
     uint32_t* d_live = nullptr;  // per-bounce live counters
     int live_slots = 0;
     // timing
@@ -502,9 +476,7 @@ void free_wavefront(hpt_ctx* ctx) {
         (void)hipFree(p);
         p = nullptr;
     }
-    (void)hipFree(ctx->d_hits);
     (void)hipFree(ctx->d_live);
-    ctx->d_hits = nullptr;
     ctx->d_live = nullptr;
     ctx->wf_allocated = 0;
     ctx->live_slots = 0;
@@ -516,11 +488,8 @@ int ensure_wavefront(hpt_ctx* ctx, uint64_t paths, int max_depth) {
             (void)hipFree(p);
             p = nullptr;
         }
-        (void)hipFree(ctx->d_hits);
-        ctx->d_hits = nullptr;
-        ctx->wf_allocated = 0;
+                ctx->wf_allocated = 0;
         for (auto& p : ctx->d_wf) HIP_TRY(hipMalloc((void**)&p, paths * sizeof(float4)));
-        HIP_TRY(hipMalloc((void**)&ctx->d_hits, paths * sizeof(int2)));
         ctx->wf_allocated = paths;
     }
     if (ctx->live_slots < max_depth + 1) {
@@ -969,11 +938,10 @@ int hpt_render(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sample
                 const WfQueue& qi = q[it & 1];
                 const WfQueue& qo = q[(it + 1) & 1];
                 HPT_DISPATCH_SCENE(S.variant, {
-                    hipLaunchKernelGGL((k_wf_extend<kS>), dim3(grid), dim3(wblock), lds_bytes(S, wblock), stream, S, qi, ctx->d_live + it, ctx->d_hits, ctx->d_stats);
-                    hipLaunchKernelGGL((k_wf_shade<kS>), dim3(grid), dim3(wblock), lds_bytes(S, wblock), stream, S, max_depth, qi, ctx->d_hits, ctx->d_live + it, qo, ctx->d_live + it + 1, accum, ctx->d_stats);
+                    hipLaunchKernelGGL((k_wf_bounce<kS>), dim3(grid), dim3(wblock), lds_bytes(S, wblock), stream, S, max_depth, qi, ctx->d_live + it, qo, ctx->d_live + it + 1, accum, ctx->d_stats);
                 })
                 HIP_TRY(hipGetLastError());
-                launches += 2;
+                ++launches;
             }
         }
     }

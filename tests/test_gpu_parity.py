@@ -208,7 +208,7 @@ def test_wavefront_small_capacity_batches(hp, oracle, gpu_ctx):
         gpu_ctx.render(2, 256, depth, 0, spp)
         got = gpu_ctx.resolve(spp)
     finally:
-        gpu_ctx.set_wavefront_capacity(1 << 22)
+        gpu_ctx.set_wavefront_capacity(1 << 24)
     want_acc, _ = oracle.cornell(w, h).render(RNG_PHILOX, TRIG_PORTABLE, depth, spp, fixed=True)
     assert np.array_equal(got.view(np.int32), oracle.resolve(want_acc, spp).view(np.int32))
 
