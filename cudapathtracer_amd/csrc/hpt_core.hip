@@ -283,70 +283,107 @@ __device__ __forceinline__ void wf_store(const WfQueue& q, size_t i, const Path&
     q.c[i] = make_float4(p.thr.x, p.thr.y, p.thr.z, __uint_as_float(p.sample));
     q.d[i] = make_float4(p.rad.x, p.rad.y, p.rad.z, __uint_as_float((uint32_t)p.depth | (p.specular ? 0x80000000u : 0u)));
 }
-__device__ __forceinline__ void wf_load(const WfQueue& q, size_t i, Path& p) {
-    const float4 a = q.a[i], b = q.b[i], c = q.c[i], d = q.d[i];
-    p.o = mk(a.x, a.y, a.z);
-    p.pdf = a.w;
-    p.d = mk(b.x, b.y, b.z);
-    p.pixel = __float_as_uint(b.w);
-    p.thr = mk(c.x, c.y, c.z);
-    p.sample = __float_as_uint(c.w);
-    p.rad = mk(d.x, d.y, d.z);
-    const uint32_t f = __float_as_uint(d.w);
+
+struct WfRecord {
+    float4 a, b, c, d;
+};
+// record i of the segment that starts at `base` (zeros beyond the segment's live count)
+__device__ __forceinline__ WfRecord wf_fetch(const WfQueue& q, size_t base, uint32_t i, uint32_t count) {
+    WfRecord r;
+    r.a = r.b = r.c = r.d = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < count) {
+        r.a = q.a[base + i];
+        r.b = q.b[base + i];
+        r.c = q.c[base + i];
+        r.d = q.d[base + i];
+    }
+    return r;
+}
+__device__ __forceinline__ void wf_unpack(const WfRecord& r, Path& p) {
+    p.o = mk(r.a.x, r.a.y, r.a.z);
+    p.pdf = r.a.w;
+    p.d = mk(r.b.x, r.b.y, r.b.z);
+    p.pixel = __float_as_uint(r.b.w);
+    p.thr = mk(r.c.x, r.c.y, r.c.z);
+    p.sample = __float_as_uint(r.c.w);
+    p.rad = mk(r.d.x, r.d.y, r.d.z);
+    const uint32_t f = __float_as_uint(r.d.w);
     p.depth = (int)(f & 0x7FFFFFFFu);
     p.specular = (f >> 31) != 0;
 }
 
-// GenerateCameraRay (gpu_path_tracer/CudaPathTrace.cu:34-62) for paths
-// [first, first + count) of the batch's linear path index space
-// (sample-major; the low index walks 8x8 pixel tiles).
+// Wavefront queues are split into one SEGMENT per workgroup: workgroup b owns records
+// [b * seg, (b + 1) * seg) of both queues and the counter live[bounce][b].  A path stays in the
+// segment it was generated into, so compaction needs no global counter: the workgroup reserves
+// output slots with an LDS atomic (a single global counter serialises one atomic per wave and
+// bounce, 12 ns each: that alone took as long as the whole render).  Paths are dealt to the
+// segments in groups of 64 round-robin, so every segment holds the same mix of pixels and the
+// segments drain at the same rate.
+
+// GenerateCameraRay (gpu_path_tracer/CudaPathTrace.cu:34-62) for paths [first, first + count) of
+// the render's linear path index space (sample-major; the low index walks 8x8 pixel tiles).
+// Group g (64 consecutive paths = one pixel tile of one sample) goes to position k = g / G of
+// segment (g + k) % G, G = gridDim.x: the skew by k keeps a segment from collecting the same
+// tile column of every sample when G divides the number of tiles.
 __global__ void k_wf_generate(DevScene S, uint32_t s_begin, uint64_t first, uint32_t count, uint32_t lanes_per_sample,
-                              WfQueue q, uint32_t* __restrict__ live_count, unsigned long long* __restrict__ stats) {
-    const uint32_t stride = gridDim.x * blockDim.x;
+                              uint32_t seg, WfQueue q, uint32_t* __restrict__ live, unsigned long long* __restrict__ stats) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, waves = (blockDim.x + 63u) >> 6;
+    const uint32_t groups = (count + 63u) >> 6, G = gridDim.x;
+    const uint32_t rows = groups / G, rem = groups % G;  // full rows of G groups, groups of the last row
+    const uint32_t mine = rows + ((blockIdx.x + G - rows % G) % G < rem ? 1u : 0u);  // groups of this segment
     uint32_t made = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
-        const uint64_t g = first + i;
-        const uint32_t s = s_begin + (uint32_t)(g / lanes_per_sample);
-        uint32_t pixel;
-        const bool valid = lane_to_pixel(S, (uint32_t)(g % lanes_per_sample), pixel);
-        // lanes of partial edge tiles own no pixel: they get a dead record
-        // (depth = max) that the first shade pass drops without tracing
-        Path p;
-        if (valid) {
-            generate_camera_path(S, pixel, s, p);
-            ++made;
-        } else {
-            p.o = p.d = p.thr = p.rad = mk(0.f);
-            p.pdf = 0.f;
-            p.depth = 0x7FFFFFFF;
-            p.specular = false;
-            p.pixel = 0xFFFFFFFFu;
-            p.sample = s;
+    if (lane < min(64u, blockDim.x - wave * 64u)) {  // (always, for the block sizes the host uses: multiples of 64)
+        for (uint32_t k = wave; k < mine; k += waves) {
+            const uint32_t i = (k * G + (blockIdx.x + G - k % G) % G) * 64u + lane;  // path of the batch
+            Path p;
+            bool valid = false;
+            uint32_t sample = s_begin;
+            if (i < count) {
+                const uint64_t g = first + i;
+                sample = s_begin + (uint32_t)(g / lanes_per_sample);
+                uint32_t pixel;
+                valid = lane_to_pixel(S, (uint32_t)(g % lanes_per_sample), pixel);
+                if (valid) generate_camera_path(S, pixel, sample, p);
+            }
+            if (valid) {
+                ++made;
+            } else {
+                // lanes of partial edge tiles (and the tail of the last group) own no pixel: they get
+                // a dead record that the first bounce drops without tracing
+                p.o = p.d = p.thr = p.rad = mk(0.f);
+                p.pdf = 0.f;
+                p.depth = 0x7FFFFFFF;
+                p.specular = false;
+                p.pixel = 0xFFFFFFFFu;
+                p.sample = sample;
+            }
+            wf_store(q, (size_t)blockIdx.x * seg + k * 64u + lane, p);
         }
-        wf_store(q, i, p);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) *live_count = count;
+    if (threadIdx.x == 0) live[blockIdx.x] = mine * 64u;
     stat_add(stats + kStatPaths, made);
 }
 
 // One bounce of every live path: ComputeIntersections + IntegratePathSegment + the two thrust
 // compactions + FinalGather (gpu_path_tracer/CudaPathTrace.cu:64-111, :149-157) in one pass.
-// A lane loads a path record, finds its closest hit, shades it (light sample with the inline
-// any-hit shadow query, BSDF sample) and then either appends the survivor to the other queue or
-// adds the finished path's radiance to its pixel (int64 atomics).  Survivors are compacted with
-// __ballot + prefix popcount and one atomicAdd per wave.  The live count stays on the device:
-// the kernel is grid-stride over *live_in, workgroups beyond it exit before staging the scene,
-// the host never waits between bounces.
+// A lane takes a path record of its workgroup's segment, finds the closest hit, shades it (light
+// sample with the inline any-hit shadow query, BSDF sample) and then either appends the survivor
+// to the segment of the other queue or adds the finished path's radiance to its pixel (int64
+// atomics).  Survivors are compacted with __ballot + prefix popcount and one LDS atomic per
+// wave.  The live counts stay on the device: the host never waits between bounces.
 template <int kScene>
 __global__ void __launch_bounds__(256)
-k_wf_bounce(DevScene S, int max_depth, WfQueue q_in, const uint32_t* __restrict__ live_in, WfQueue q_out,
+k_wf_bounce(DevScene S, int max_depth, uint32_t seg, WfQueue q_in, const uint32_t* __restrict__ live_in, WfQueue q_out,
             uint32_t* __restrict__ live_out, int64_t* __restrict__ accum, unsigned long long* __restrict__ stats) {
     extern __shared__ float4 lds[];
-    const uint32_t count = *live_in;
-    if (blockIdx.x * blockDim.x >= count) return;  // late bounces: most workgroups have no path left
-    stage_scene<kScene>(S, lds);
-    const uint32_t stride = gridDim.x * blockDim.x;
+    __shared__ uint32_t s_out;
+    const uint32_t count = live_in[blockIdx.x];
+    if (count == 0) return;  // live_out was cleared by the host
+    if (threadIdx.x == 0) s_out = 0;
+    stage_scene<kScene>(S, lds);  // ends with a barrier (variants without LDS records: below)
+    if constexpr (kScene == kSceneGlobal || kScene == kScenePair) __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
+    const size_t seg_base = (size_t)blockIdx.x * seg;
     const TriQueue tq = make_tri_queue(reinterpret_cast<uint32_t*>(lds + S.lds_float4s));
     uint32_t n_closest = 0, n_shadow = 0;
 #ifdef HPT_PROFILE
@@ -356,14 +393,15 @@ k_wf_bounce(DevScene S, int max_depth, WfQueue q_in, const uint32_t* __restrict_
 #endif
     // all lanes of a wave run the same number of iterations so that the ballot below always
     // sees the whole wave
-    const uint32_t wave_first = (blockIdx.x * blockDim.x + threadIdx.x) - lane;
-    for (uint32_t base = wave_first; base < count; base += stride) {
+    const uint32_t wave_first = threadIdx.x - lane;
+    for (uint32_t base = wave_first; base < count; base += blockDim.x) {
         const uint32_t i = base + lane;
+        const WfRecord cur = wf_fetch(q_in, seg_base, i, count);
         bool keep = false;
         Path p;
         if (i < count) {
-            wf_load(q_in, i, p);
-            if (p.pixel != 0xFFFFFFFFu) {  // not the dead record of a partial edge tile
+            wf_unpack(cur, p);
+            if (p.pixel != 0xFFFFFFFFu) {  // not a dead record
                 int tri;
                 double t;
                 ++n_closest;
@@ -376,11 +414,13 @@ k_wf_bounce(DevScene S, int max_depth, WfQueue q_in, const uint32_t* __restrict_
         if (mask) {
             const int leader = __ffsll((long long)mask) - 1;
             uint32_t slot = 0;
-            if ((int)lane == leader) slot = atomicAdd(live_out, (uint32_t)__popcll(mask));
+            if ((int)lane == leader) slot = atomicAdd(&s_out, (uint32_t)__popcll(mask));
             slot = __shfl(slot, leader);
-            if (keep) wf_store(q_out, slot + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)), p);
+            if (keep) wf_store(q_out, seg_base + slot + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)), p);
         }
     }
+    __syncthreads();
+    if (threadIdx.x == 0) live_out[blockIdx.x] = s_out;
     stat_add(stats + kStatClosest, n_closest);
     stat_add(stats + kStatShadow, n_shadow);
 }
@@ -431,7 +471,7 @@ struct hpt_ctx {
     uint64_t wf_allocated = 0;
     float4* d_wf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     uint32_t* d_live = nullptr;  // per-bounce live counters
-    int live_slots = 0;
+    size_t live_slots = 0;
     // timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;
     std::vector<hipEvent_t> free_events;
@@ -482,7 +522,7 @@ void free_wavefront(hpt_ctx* ctx) {
     ctx->live_slots = 0;
 }
 
-int ensure_wavefront(hpt_ctx* ctx, uint64_t paths, int max_depth) {
+int ensure_wavefront(hpt_ctx* ctx, uint64_t paths, int max_depth, uint32_t segments) {
     if (ctx->wf_allocated < paths) {
         for (auto& p : ctx->d_wf) {
             (void)hipFree(p);
@@ -492,12 +532,13 @@ int ensure_wavefront(hpt_ctx* ctx, uint64_t paths, int max_depth) {
         for (auto& p : ctx->d_wf) HIP_TRY(hipMalloc((void**)&p, paths * sizeof(float4)));
         ctx->wf_allocated = paths;
     }
-    if (ctx->live_slots < max_depth + 1) {
+    const size_t want = (size_t)(max_depth + 1) * segments;  // one live counter per bounce and segment
+    if (ctx->live_slots < want) {
         (void)hipFree(ctx->d_live);
         ctx->d_live = nullptr;
         ctx->live_slots = 0;
-        HIP_TRY(hipMalloc((void**)&ctx->d_live, (size_t)(max_depth + 1) * sizeof(uint32_t)));
-        ctx->live_slots = max_depth + 1;
+        HIP_TRY(hipMalloc((void**)&ctx->d_live, want * sizeof(uint32_t)));
+        ctx->live_slots = want;
     }
     return HPT_OK;
 }
@@ -925,20 +966,30 @@ int hpt_render(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sample
         const int wblock = block > 256 ? 256 : block;
         const uint64_t total = lanes * (uint64_t)sample_count;
         const uint64_t cap = ctx->wf_capacity < total ? ctx->wf_capacity : ((total + 63ull) & ~63ull);
-        if (int rc = ensure_wavefront(ctx, cap, max_depth)) return rc;
+        // one queue segment per workgroup; exactly the workgroups that are resident at once
+        int per_cu = 0;
+        HPT_DISPATCH_SCENE(S.variant, {
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_bounce<kS>, wblock, lds_bytes(S, wblock)));
+        })
+        if (per_cu < 1) return fail(HPT_ERR_INVALID_ARGUMENT, "the wavefront kernel does not fit a compute unit with %u bytes of LDS", lds_bytes(S, wblock));
+        const uint64_t cap_groups = (cap + 63ull) >> 6;
+        const uint32_t segments = (uint32_t)std::min<uint64_t>((uint64_t)per_cu * (uint64_t)ctx->num_cus, cap_groups);
+        const uint32_t seg = (uint32_t)((cap_groups + segments - 1ull) / segments) * 64u;  // records per segment
+        if (int rc = ensure_wavefront(ctx, (uint64_t)seg * segments, max_depth, segments)) return rc;
         WfQueue q[2] = {{ctx->d_wf[0], ctx->d_wf[1], ctx->d_wf[2], ctx->d_wf[3]}, {ctx->d_wf[4], ctx->d_wf[5], ctx->d_wf[6], ctx->d_wf[7]}};
+        // the generate kernel needs whole waves
+        const int gblock = (wblock + 63) & ~63;
         for (uint64_t first = 0; first < total; first += cap) {
             const uint32_t count = (uint32_t)((total - first < cap) ? total - first : cap);
-            const int grid = grid_for(ctx, count, wblock);
-            HIP_TRY(hipMemsetAsync(ctx->d_live, 0, (size_t)(max_depth + 1) * sizeof(uint32_t), stream));
-            hipLaunchKernelGGL(k_wf_generate, dim3(grid), dim3(wblock), 0, stream, S, sample_begin, first, count, (uint32_t)lanes, q[0], ctx->d_live, ctx->d_stats);
+            HIP_TRY(hipMemsetAsync(ctx->d_live, 0, (size_t)(max_depth + 1) * segments * sizeof(uint32_t), stream));
+            hipLaunchKernelGGL(k_wf_generate, dim3(segments), dim3(gblock), 0, stream, S, sample_begin, first, count, (uint32_t)lanes, seg, q[0], ctx->d_live, ctx->d_stats);
             HIP_TRY(hipGetLastError());
             ++launches;
             for (int it = 0; it < max_depth; ++it) {
                 const WfQueue& qi = q[it & 1];
                 const WfQueue& qo = q[(it + 1) & 1];
                 HPT_DISPATCH_SCENE(S.variant, {
-                    hipLaunchKernelGGL((k_wf_bounce<kS>), dim3(grid), dim3(wblock), lds_bytes(S, wblock), stream, S, max_depth, qi, ctx->d_live + it, qo, ctx->d_live + it + 1, accum, ctx->d_stats);
+                    hipLaunchKernelGGL((k_wf_bounce<kS>), dim3(segments), dim3(wblock), lds_bytes(S, wblock), stream, S, max_depth, seg, qi, ctx->d_live + (size_t)it * segments, qo, ctx->d_live + (size_t)(it + 1) * segments, accum, ctx->d_stats);
                 })
                 HIP_TRY(hipGetLastError());
                 ++launches;
