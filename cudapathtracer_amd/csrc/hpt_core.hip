@@ -34,7 +34,7 @@ using namespace hpt;
 namespace {
 
 constexpr uint32_t kLdsLimit = 32u * 1024u;
-constexpr uint32_t kLdsLimitTiny = 40u * 1024u;  // eight node copies of a 64-triangle scene (127 nodes) + its triangles
+constexpr uint32_t kLdsLimitTiny = 44u * 1024u;  // nine node copies of a 64-triangle scene (127 nodes) + its triangles
 constexpr uint32_t kMaxLdsPerBlock = 160u * 1024u;  // LDS of a gfx950 compute unit; one workgroup may use all of it
 constexpr uint32_t kMaxStackDepth = 40;  // per-lane stack entries (4 B each in LDS); median-split trees need ~log2(triangles)
 constexpr int kStatClosest = 0, kStatShadow = 1, kStatPaths = 2, kNumStats = 4;
@@ -457,6 +457,8 @@ struct hpt_ctx {
     float4* d_tris = nullptr;
     float4* d_tri_v12 = nullptr;
     float4* d_pairs = nullptr;
+    float4* d_oct_nodes = nullptr;
+    uint32_t* d_oct_table = nullptr;
     DevMaterial* d_mats = nullptr;
     DevLight* d_lights = nullptr;
     // accumulation + stats
@@ -494,6 +496,8 @@ void free_scene(hpt_ctx* ctx) {
     (void)hipFree(ctx->d_tris);
     (void)hipFree(ctx->d_tri_v12);
     (void)hipFree(ctx->d_pairs);
+    (void)hipFree(ctx->d_oct_nodes);
+    (void)hipFree(ctx->d_oct_table);
     (void)hipFree(ctx->d_mats);
     (void)hipFree(ctx->d_lights);
     (void)hipFree(ctx->d_accum);
@@ -503,6 +507,8 @@ void free_scene(hpt_ctx* ctx) {
     ctx->d_tris = nullptr;
     ctx->d_tri_v12 = nullptr;
     ctx->d_pairs = nullptr;
+    ctx->d_oct_nodes = nullptr;
+    ctx->d_oct_table = nullptr;
     ctx->d_mats = nullptr;
     ctx->d_lights = nullptr;
     ctx->d_accum = nullptr;
@@ -588,6 +594,124 @@ int validate_scene(const hpt_scene_desc* sc) {
             return fail(HPT_ERR_INVALID_ARGUMENT, "light %u: bad node/material index", l);
     }
     return HPT_OK;
+}
+
+// The nine node-array copies of the marking variants (layout: stage_scene in hpt_device.h).
+// out_nodes: 9 * nn records of 8 floats; out_table: 32 dwords.
+//
+// A triangle with normal n is rejected by Triangle::getIntersection's first test,
+// dot(d, n) > 0 (common/Triangle.hpp:168-169), for EVERY ray of a sign octant (s_i = sign of
+// d_i, no d_i zero) when n_i * s_i >= 0 for all i and n_i * s_i >= 0.5 for one i: no product
+// d_i * n_i is negative and that one is at least 0.5 * |d_i| > 0 (|d_i| >= 2^-128 for a finite
+// reciprocal, so the product does not underflow to zero).  It passes the test for every ray of
+// the octant when n_i * s_i <= 0 for all i.  Subtrees that hold only always-rejected triangles
+// are left out of the octant's copy, and an interior node with one such child is replaced by
+// its other child when that child's box lies inside its own: then the child's slab test can
+// only succeed where the parent's would (float subtraction and multiplication are monotone),
+// so the set of triangles reached is unchanged.
+void build_octant_copies(const hpt_scene_desc* sc, bool leaf_bits, std::vector<float>& out_nodes, std::vector<uint32_t>& out_table) {
+    const uint32_t nn = sc->num_nodes, nt = sc->num_tris;
+    out_nodes.assign((size_t)9 * nn * 8, 0.f);
+    out_table.assign(32, 0u);
+    auto node_int = [&](uint32_t i, int word) {
+        int32_t v;
+        std::memcpy(&v, &sc->nodes[8 * (size_t)i + word], 4);
+        return v;
+    };
+    struct Rec {
+        float lo[3], hi[3];
+        uint32_t miss;  // index of the miss target inside the copy
+        int32_t tri;
+    };
+    for (uint32_t k = 0; k < 9; ++k) {
+        const bool whole = k == 8;
+        const float sgn[3] = {(k & 1u) ? -1.f : 1.f, (k & 2u) ? -1.f : 1.f, (k & 4u) ? -1.f : 1.f};
+        std::vector<uint8_t> rejected(nt, 0), passes(nt, 0);
+        if (!whole)
+            for (uint32_t t = 0; t < nt; ++t) {
+                const float* n = &sc->tris[16 * (size_t)t + 12];
+                const float a = n[0] * sgn[0], b = n[1] * sgn[1], c = n[2] * sgn[2];
+                rejected[t] = a >= 0.f && b >= 0.f && c >= 0.f && (a >= 0.5f || b >= 0.5f || c >= 0.5f);
+                passes[t] = a <= 0.f && b <= 0.f && c <= 0.f;
+            }
+        // live[i]: the subtree of node i holds a triangle that is not always rejected
+        std::vector<uint8_t> live(nn, 0);
+        for (uint32_t i = nn; i-- > 0;) {
+            const int32_t tri = node_int(i, 7);
+            if (tri >= 0) live[i] = !rejected[tri];
+            else live[i] = live[i + 1] || live[(uint32_t)node_int(i + 1, 3)];
+        }
+        auto inside = [&](uint32_t child, uint32_t parent) {
+            for (int c = 0; c < 3; ++c)
+                if (!(sc->nodes[8 * (size_t)child + c] >= sc->nodes[8 * (size_t)parent + c] &&
+                      sc->nodes[8 * (size_t)child + 4 + c] <= sc->nodes[8 * (size_t)parent + 4 + c]))
+                    return false;
+            return true;
+        };
+        std::vector<Rec> recs;
+        // explicit stack of (node, index of the record to patch when the subtree is complete | ~0u)
+        struct Item {
+            uint32_t node;
+            bool close;
+            uint32_t rec;
+        };
+        std::vector<Item> stack;
+        stack.push_back({0u, false, 0u});
+        while (!stack.empty()) {
+            const Item it = stack.back();
+            stack.pop_back();
+            if (it.close) {
+                recs[it.rec].miss = (uint32_t)recs.size();
+                continue;
+            }
+            uint32_t i = it.node;
+            if (!live[i]) continue;
+            // skip interior nodes that only lead to one live child lying inside them
+            for (;;) {
+                if (node_int(i, 7) >= 0) break;
+                const uint32_t l = i + 1, r = (uint32_t)node_int(l, 3);
+                if (live[l] && live[r]) break;
+                const uint32_t only = live[l] ? l : r;
+                if (!inside(only, i)) break;
+                i = only;
+            }
+            Rec rc;
+            for (int c = 0; c < 3; ++c) {
+                rc.lo[c] = sc->nodes[8 * (size_t)i + c];
+                rc.hi[c] = sc->nodes[8 * (size_t)i + 4 + c];
+            }
+            rc.tri = node_int(i, 7);
+            rc.miss = (uint32_t)recs.size() + 1u;  // leaf: the next record
+            recs.push_back(rc);
+            if (rc.tri < 0) {
+                const uint32_t l = i + 1, r = (uint32_t)node_int(l, 3);
+                stack.push_back({0u, true, (uint32_t)recs.size() - 1u});
+                if (live[r]) stack.push_back({r, false, 0u});
+                if (live[l]) stack.push_back({l, false, 0u});
+            }
+        }
+        out_table[k] = (uint32_t)recs.size();
+        for (size_t j = 0; j < recs.size(); ++j) {
+            float* q = &out_nodes[((size_t)k * nn + j) * 8];
+            for (int c = 0; c < 3; ++c) {
+                const bool neg = !whole && (k >> c) & 1u;
+                q[c] = neg ? recs[j].hi[c] : recs[j].lo[c];
+                q[4 + c] = neg ? recs[j].lo[c] : recs[j].hi[c];
+            }
+            const uint32_t link = (k * nn + recs[j].miss) * 32u;
+            std::memcpy(&q[3], &link, 4);
+            uint32_t leaf = (uint32_t)recs[j].tri;
+            if (leaf_bits) leaf = recs[j].tri >= 0 ? 1u << recs[j].tri : 0u;
+            std::memcpy(&q[7], &leaf, 4);
+        }
+        if (!whole) {
+            unsigned long long undecided = 0;
+            for (uint32_t t = 0; t < nt && t < 64; ++t)
+                if (!rejected[t] && !passes[t]) undecided |= 1ull << t;
+            out_table[16 + 2 * k] = (uint32_t)undecided;
+            out_table[17 + 2 * k] = (uint32_t)(undecided >> 32);
+        }
+    }
 }
 
 hipEvent_t take_event(hpt_ctx* ctx) {
@@ -840,7 +964,7 @@ int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* sc) {
         S.root_hi[c] = sc->nodes[4 + c];
     }
     const uint64_t f4 = 2ull * nn + 4ull * nt;             // threaded nodes + triangles
-    const uint64_t f4_tiny = 16ull * nn + 4ull * nt;       // eight octant copies of the nodes + triangles
+    const uint64_t f4_tiny = 18ull * nn + 4ull * nt + 8ull;  // nine copies of the nodes + triangles + table
     const uint64_t f4_pair = 4ull * num_pairs + 4ull * nt;  // two-child records + triangles
     const bool fits = f4 * 16ull <= kLdsLimit, fits_pair = f4_pair * 16ull <= kLdsLimit;
     const bool fits_tiny = f4_tiny * 16ull <= kLdsLimitTiny;
@@ -857,6 +981,17 @@ int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* sc) {
         else if (v == kSceneTiny32 && fits_tiny && nt <= 32) S.variant = kSceneTiny32;
         else if (v == kScenePair && pair_ok) S.variant = kScenePair;
         else if (v == kScenePairLds && pair_ok && fits_pair) S.variant = kScenePairLds;
+    }
+    if (S.variant == kSceneTiny32 || S.variant == kSceneTiny64) {
+        std::vector<float> oct_nodes;
+        std::vector<uint32_t> oct_table;
+        build_octant_copies(sc, S.variant == kSceneTiny32, oct_nodes, oct_table);
+        HIP_TRY(hipMalloc((void**)&ctx->d_oct_nodes, oct_nodes.size() * 4));
+        HIP_TRY(hipMalloc((void**)&ctx->d_oct_table, oct_table.size() * 4));
+        HIP_TRY(hipMemcpy(ctx->d_oct_nodes, oct_nodes.data(), oct_nodes.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ctx->d_oct_table, oct_table.data(), oct_table.size() * 4, hipMemcpyHostToDevice));
+        S.oct_nodes = ctx->d_oct_nodes;
+        S.oct_table = ctx->d_oct_table;
     }
     switch (S.variant) {
     case kSceneLds: S.lds_float4s = (uint32_t)f4; break;

@@ -221,6 +221,11 @@ struct DevScene {
     // interior node, in pre-order:
     //   (left.pMin, left ref) (left.pMax, right ref) (right.pMin, -) (right.pMax, -)
     // ref >= 0: index of the child's own record; ref < 0: the child is a leaf, triangle ~ref
+    // marking variants: nine pre-processed copies of the node array (see stage_scene) and their
+    // table: dword k = nodes in copy k, dwords 16 + 2k / 17 + 2k = triangles whose back-face test
+    // is still needed for a ray of sign octant k
+    const float4* oct_nodes;
+    const uint32_t* oct_table;
     const float4* pairs;
     uint32_t num_pairs;
     uint32_t stack_depth;  // entries of the per-lane traversal stack that no ray can exceed
@@ -272,29 +277,28 @@ HD void stage_scene(const DevScene& S, float4* lds) {
         for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) lds[nn + i] = S.tris[i];
         __syncthreads();
     } else {
-        // Marking variants: EIGHT copies of the node array, one per sign octant of the ray
-        // direction (bit 0/1/2 = x/y/z negative).  Copy k holds per node
-        //   (near.xyz, LDS address of the miss target inside copy k) (far.xyz, leaf word)
-        // with near/far = the slab planes a ray of that octant enters/leaves through
-        // (Bounds3::IntersectP's dirIsNeg selection, common/Bounds3.hpp:100-116, done once at
-        // staging instead of per test).  Leaf word: the triangle's bit in the pending mask
-        // (32-triangle variants; 0 = interior) or the triangle index / -1 (64).
-        constexpr bool kLeafBits = (kScene == kSceneTiny32);
+        // Marking variants: NINE copies of the node array, prepared at upload (build_octant_copies in
+        // hpt_core.hip), nn records of 32 bytes each.  Copy k < 8 serves rays of sign octant k
+        // (bit 0/1/2 = x/y/z of the direction negative) and holds, in pre-order,
+        //   (near.xyz, link) (far.xyz, leaf word)
+        // near/far = the slab planes a ray of that octant enters/leaves through (the dirIsNeg
+        // selection of Bounds3::IntersectP, common/Bounds3.hpp:100-116, done once instead of per
+        // test); subtrees whose triangles all face away from every ray of the octant are left
+        // out (the reference walks them, but Triangle::getIntersection rejects each of their
+        // triangles at its first line, common/Triangle.hpp:168-169).  Copy 8 is the whole tree
+        // with near = pMin, far = pMax for rays with a zero direction component.  link = byte
+        // offset of the miss target from the start of the copies; it becomes an LDS address here.
+        // Leaf word: the triangle's bit in the pending mask (32-triangle variant; 0 = interior)
+        // or the triangle index / -1 (64).
         const uint32_t nn = S.num_nodes, nt = 4u * S.num_tris;
-        for (uint32_t i = threadIdx.x; i < 8u * nn; i += blockDim.x) {
-            const uint32_t k = i / nn, n = i - k * nn;
-            const float4 lo = S.nodes[2u * n], hi = S.nodes[2u * n + 1u];
-            const bool sx = k & 1u, sy = k & 2u, sz = k & 4u;
-            float leaf = hi.w;
-            if (kLeafBits) {
-                const int tri = __float_as_int(hi.w);
-                leaf = __uint_as_float(tri >= 0 ? 1u << tri : 0u);
-            }
-            const uint32_t miss_at = lds_address(lds) + (k * nn + (uint32_t)__float_as_int(lo.w)) * 32u;
-            lds[2u * i] = make_float4(sx ? hi.x : lo.x, sy ? hi.y : lo.y, sz ? hi.z : lo.z, __uint_as_float(miss_at));
-            lds[2u * i + 1u] = make_float4(sx ? lo.x : hi.x, sy ? lo.y : hi.y, sz ? lo.z : hi.z, leaf);
+        const uint32_t base = lds_address(lds);
+        for (uint32_t i = threadIdx.x; i < 18u * nn; i += blockDim.x) {
+            float4 v = S.oct_nodes[i];
+            if (!(i & 1u)) v.w = __uint_as_float(__float_as_uint(v.w) + base);
+            lds[i] = v;
         }
-        for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) lds[16u * nn + i] = S.tris[i];
+        for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) lds[18u * nn + i] = S.tris[i];
+        if (threadIdx.x < 32u) reinterpret_cast<uint32_t*>(lds + 18u * nn + nt)[threadIdx.x] = S.oct_table[threadIdx.x];
         __syncthreads();
     }
 }
@@ -389,8 +393,8 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
         N = lds;
         T = lds + 2u * S.num_nodes;
     } else if constexpr (kScene != kSceneGlobal) {
-        N = lds;  // eight octant copies of the nodes, see stage_scene
-        T = lds + 16u * S.num_nodes;
+        N = lds;  // nine copies of the nodes, see stage_scene
+        T = lds + 18u * S.num_nodes;
     } else {
         N = S.nodes;
         T = S.tris;
@@ -410,11 +414,13 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
         PROF_T0();
         const bool finite = fabsf(inv.x) < kInf && fabsf(inv.y) < kInf && fabsf(inv.z) < kInf;
         const uint32_t nbase = lds_address(N), copy_bytes = S.num_nodes * 32u;
+        const uint32_t* table = reinterpret_cast<const uint32_t*>(T + 4u * S.num_tris);
+        mask_t undecided;  // marked triangles whose back-face test (Triangle.hpp:168-169) is still to be done
         if (finite) {
             // walk the copy of this ray's octant; `at` is the node's LDS address, links are addresses too
             const uint32_t oct = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
             uint32_t at = nbase + oct * copy_bytes;
-            const uint32_t stop = at + copy_bytes;
+            const uint32_t stop = at + table[oct] * 32u;
             while (at < stop) {
                 PROF_ITER(kShadow ? kProfBoxS : kProfBoxC);
                 const float4 nr = lds_read(at), fr = lds_read(at + 16u);
@@ -430,9 +436,12 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
                 }
                 at = hit ? at + 32u : __float_as_uint(nr.w);
             }
-        } else {  // a direction component is 0 (or denormal): the reference's NaN-aware sequence, on copy 0 (near = pMin)
-            uint32_t at = nbase;
-            while (at < nbase + copy_bytes) {
+            if constexpr (kMask32) undecided = pending & table[16u + 2u * oct];
+            else undecided = pending & ((mask_t)table[16u + 2u * oct] | ((mask_t)table[17u + 2u * oct] << 32));
+        } else {  // a direction component is 0 (or denormal): the reference's NaN-aware sequence on the whole tree
+            uint32_t at = nbase + 8u * copy_bytes;
+            const uint32_t stop = at + copy_bytes;
+            while (at < stop) {
                 const float4 lo = lds_read(at), hi = lds_read(at + 16u);
                 const bool hit = box_hit(lo, hi, o, inv, nx, ny, nz);
                 if constexpr (kMask32) {
@@ -443,11 +452,12 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
                 }
                 at = hit ? at + 32u : __float_as_uint(lo.w);
             }
+            undecided = pending;
         }
         PROF_T1(kShadow ? kProfBoxS : kProfBoxC);
-        // cheap filter first: drop back-facing triangles (Triangle.hpp:168-169), so
-        // that the expensive rounds below are only as many as the busiest lane needs
-        for (mask_t m = pending; m;) {
+        // cheap filter first: drop back-facing triangles, so that the expensive rounds below are
+        // only as many as the busiest lane needs.  Most triangles are decided by the octant alone.
+        for (mask_t m = undecided; m;) {
             const int tri = kMask32 ? __ffs((int)m) - 1 : __ffsll((long long)m) - 1;
             const mask_t rest = m & (m - 1);
             if (dot(d, xyz(T[4 * tri + 3])) > 0) pending ^= m ^ rest;  // m ^ rest = the bit just examined
