@@ -43,17 +43,18 @@ def _shadow_batch(n, seed, down=False):
     return (p + d * np.float32(1e-5)).astype(np.float32), d, np.ones(n, np.uint8), ln.astype(np.float64)
 
 
-@pytest.mark.parametrize("name", ["bunny", "heightfield128", "heightfield8"])
+@pytest.mark.parametrize("name", ["bunny", "heightfield128", "heightfield8", "heightfield4"])
 def test_scene_hits_and_images(hp, oracle, gpu_ctx, name):
     """bunny / heightfield128: two-child records read through L1/L2; heightfield8 (140 triangles):
-    the same records staged in LDS."""
+    the same records staged in LDS; heightfield4 (44 triangles): the marking variant with a
+    64-bit mask and per-octant node copies."""
     from cudapathtracer_amd import scenes
     parts = scenes.bunny_in_cornell_parts() if name == "bunny" else scenes.heightfield_in_cornell_parts(int(name[11:]))
     w, h, depth, spp = 56, 40, 6, 2
     sc = scenes._assemble(parts, w, h, depth)
     osc = _oracle_scene(oracle, parts, w, h)
     gpu_ctx.upload(sc)
-    assert gpu_ctx.stats()["variant"] == (6 if name == "heightfield8" else 5)
+    assert gpu_ctx.stats()["variant"] == {"heightfield8": 6, "heightfield4": 3}.get(name, 5)
     o, d = primary_rays(192, 192, scenes.CORNELL_CAM, osc.info()["cam_scale"])
     hit = _same_hits(gpu_ctx, osc, o, d)
     big = 4 if name == "bunny" else 4      # mesh index of the large mesh
