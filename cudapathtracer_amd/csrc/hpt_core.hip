@@ -2,20 +2,19 @@
 //
 // Kernels
 //   k_intersect_batch  closest/any-hit queries on a caller-supplied ray batch
-//   k_render_mega      mode 1: one lane per pixel runs whole paths; a lane whose
-//                      path ends starts its next sample at once, so the wave
-//                      stays full although path lengths differ from 1 to
-//                      max_depth bounces
+//   k_render_mega      mode 1: persistent waves draw (pixel tile, sample chunk) units from a
+//                      global counter; a lane whose path ends starts the next (pixel, sample)
+//                      of the wave's unit at once, so the wave stays full although path
+//                      lengths differ from 1 to max_depth bounces
 //   k_wf_generate / k_wf_bounce
-//                      mode 2: wavefront; path state lives in 64-byte SoA
-//                      records, survivors are compacted with a wave ballot +
-//                      prefix count and one atomic per wave, the live count
-//                      stays on the device (no host round trip per bounce)
+//                      mode 2: wavefront; path state lives in 64-byte SoA records in one
+//                      queue segment per workgroup, survivors are compacted with a wave
+//                      ballot + prefix count and one LDS atomic per wave, the live counts
+//                      stay on the device (no host round trip per bounce)
 //   k_resolve          fixed-point accumulators -> float RGB / spp
 //
-// Scenes whose node+triangle records fit in kLdsLimit bytes are staged into
-// LDS once per workgroup (the Cornell box: 4 KiB); larger ones are read
-// through L1/L2.
+// Small scenes are staged into LDS once per workgroup in a pre-processed form (the Cornell
+// box: 20 KiB), larger ones are read through L1/L2 as two-child records; see DevScene::variant.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
