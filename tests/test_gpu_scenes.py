@@ -74,6 +74,28 @@ def test_scene_hits_and_images(hp, oracle, gpu_ctx, name):
         assert np.array_equal(got.view(np.int32), oracle.resolve(want_acc, spp).view(np.int32)), "mode %d" % mode
 
 
+@pytest.mark.parametrize("variant", [0, 1])
+def test_forced_variants(hp, oracle, gpu_ctx, monkeypatch, variant):
+    """the variants that are no scene's default: the threaded walk through L1/L2 (0) and from
+    LDS (1), forced through the environment at upload."""
+    from cudapathtracer_amd import scenes
+    parts = scenes.heightfield_in_cornell_parts(8)
+    w, h, depth, spp = 40, 24, 5, 2
+    sc = scenes._assemble(parts, w, h, depth)
+    osc = _oracle_scene(oracle, parts, w, h)
+    monkeypatch.setenv("HPT_TRACE_VARIANT", str(variant))
+    gpu_ctx.upload(sc)
+    monkeypatch.delenv("HPT_TRACE_VARIANT")
+    assert gpu_ctx.stats()["variant"] == variant
+    _same_hits(gpu_ctx, osc, *random_rays(1 << 16, 51))
+    _same_hits(gpu_ctx, osc, *_shadow_batch(1 << 15, 52, down=True))
+    want_acc, _ = osc.render(RNG_PHILOX, TRIG_PORTABLE, depth, spp, fixed=True)
+    for mode in (1, 2):
+        gpu_ctx.accum_clear()
+        gpu_ctx.render(mode, 256, depth, 0, spp)
+        assert np.array_equal(gpu_ctx.resolve(spp).view(np.int32), oracle.resolve(want_acc, spp).view(np.int32))
+
+
 def test_million_triangle_heightfield(hp, oracle, gpu_ctx):
     """~1.0 M triangles / 2.0 M nodes: topology equal to the oracle's, hits bit-exact."""
     from cudapathtracer_amd import scenes
