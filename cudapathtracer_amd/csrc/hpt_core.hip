@@ -6,7 +6,7 @@
 //                      global counter; a lane whose path ends starts the next (pixel, sample)
 //                      of the wave's unit at once, so the wave stays full although path
 //                      lengths differ from 1 to max_depth bounces
-//   k_wf_generate / k_wf_bounce
+//   k_wf_generate / k_wf_bounces
 //                      mode 2: wavefront; path state lives in 64-byte SoA records in one
 //                      queue segment per workgroup, survivors are compacted with a wave
 //                      ballot + prefix count and one LDS atomic per wave, the live counts
@@ -363,24 +363,23 @@ __global__ void k_wf_generate(DevScene S, uint32_t s_begin, uint64_t first, uint
     stat_add(stats + kStatPaths, made);
 }
 
-// One bounce of every live path: ComputeIntersections + IntegratePathSegment + the two thrust
-// compactions + FinalGather (gpu_path_tracer/CudaPathTrace.cu:64-111, :149-157) in one pass.
-// A lane takes a path record of its workgroup's segment, finds the closest hit, shades it (light
-// sample with the inline any-hit shadow query, BSDF sample) and then either appends the survivor
-// to the segment of the other queue or adds the finished path's radiance to its pixel (int64
-// atomics).  Survivors are compacted with __ballot + prefix popcount and one LDS atomic per
-// wave.  The live counts stay on the device: the host never waits between bounces.
+// All bounces of a segment's paths: per bounce ComputeIntersections + IntegratePathSegment + the
+// two thrust compactions + FinalGather (gpu_path_tracer/CudaPathTrace.cu:64-111, :149-157) in one
+// pass.  A lane takes a path record of its workgroup's segment, finds the closest hit, shades it
+// (light sample with the inline any-hit shadow query, BSDF sample) and then either appends the
+// survivor to the segment of the other queue or adds the finished path's radiance to its pixel
+// (int64 atomics).  Survivors are compacted with __ballot + prefix popcount and one LDS atomic
+// per wave.  Segments are independent, so the bounce loop runs inside the kernel with workgroup
+// barriers only: one launch per batch, the scene staged once, no workgroup waits for another.
 template <int kScene>
 __global__ void __launch_bounds__(256)
-k_wf_bounce(DevScene S, int max_depth, uint32_t seg, WfQueue q_in, const uint32_t* __restrict__ live_in, WfQueue q_out,
-            uint32_t* __restrict__ live_out, int64_t* __restrict__ accum, unsigned long long* __restrict__ stats) {
+k_wf_bounces(DevScene S, int max_depth, uint32_t seg, WfQueue q0, WfQueue q1, const uint32_t* __restrict__ live,
+             int64_t* __restrict__ accum, unsigned long long* __restrict__ stats) {
     extern __shared__ float4 lds[];
     __shared__ uint32_t s_out;
-    const uint32_t count = live_in[blockIdx.x];
-    if (count == 0) return;  // live_out was cleared by the host
-    if (threadIdx.x == 0) s_out = 0;
-    stage_scene<kScene>(S, lds);  // ends with a barrier (variants without LDS records: below)
-    if constexpr (kScene == kSceneGlobal || kScene == kScenePair) __syncthreads();
+    uint32_t count = live[blockIdx.x];
+    if (count == 0) return;
+    stage_scene<kScene>(S, lds);
     const uint32_t lane = threadIdx.x & 63u;
     const size_t seg_base = (size_t)blockIdx.x * seg;
     const TriQueue tq = make_tri_queue(reinterpret_cast<uint32_t*>(lds + S.lds_float4s));
@@ -393,33 +392,40 @@ k_wf_bounce(DevScene S, int max_depth, uint32_t seg, WfQueue q_in, const uint32_
     // all lanes of a wave run the same number of iterations so that the ballot below always
     // sees the whole wave
     const uint32_t wave_first = threadIdx.x - lane;
-    for (uint32_t base = wave_first; base < count; base += blockDim.x) {
-        const uint32_t i = base + lane;
-        const WfRecord cur = wf_fetch(q_in, seg_base, i, count);
-        bool keep = false;
-        Path p;
-        if (i < count) {
-            wf_unpack(cur, p);
-            if (p.pixel != 0xFFFFFFFFu) {  // not a dead record
-                int tri;
-                double t;
-                ++n_closest;
-                trace<kScene, false>(S, lds, tq, p.o, p.d, 0.0, tri, t PROF_PASS);
-                keep = shade_bounce<kScene>(S, lds, tq, p, tri, t, n_shadow PROF_PASS) && p.depth < max_depth;
-                if (!keep) accumulate_pixel(accum, p.pixel, p.rad);
+    for (int bounce = 0; bounce < max_depth && count; ++bounce) {
+        const WfQueue& q_in = (bounce & 1) ? q1 : q0;
+        const WfQueue& q_out = (bounce & 1) ? q0 : q1;
+        if (threadIdx.x == 0) s_out = 0;
+        __syncthreads();  // also: the records the previous bounce stored are visible to the whole workgroup
+        for (uint32_t base = wave_first; base < count; base += blockDim.x) {
+            const uint32_t i = base + lane;
+            const WfRecord cur = wf_fetch(q_in, seg_base, i, count);
+            bool keep = false;
+            Path p;
+            if (i < count) {
+                wf_unpack(cur, p);
+                if (p.pixel != 0xFFFFFFFFu) {  // not a dead record
+                    int tri;
+                    double t;
+                    ++n_closest;
+                    trace<kScene, false>(S, lds, tq, p.o, p.d, 0.0, tri, t PROF_PASS);
+                    keep = shade_bounce<kScene>(S, lds, tq, p, tri, t, n_shadow PROF_PASS) && p.depth < max_depth;
+                    if (!keep) accumulate_pixel(accum, p.pixel, p.rad);
+                }
+            }
+            const unsigned long long mask = __ballot(keep);
+            if (mask) {
+                const int leader = __ffsll((long long)mask) - 1;
+                uint32_t slot = 0;
+                if ((int)lane == leader) slot = atomicAdd(&s_out, (uint32_t)__popcll(mask));
+                slot = __shfl(slot, leader);
+                if (keep) wf_store(q_out, seg_base + slot + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)), p);
             }
         }
-        const unsigned long long mask = __ballot(keep);
-        if (mask) {
-            const int leader = __ffsll((long long)mask) - 1;
-            uint32_t slot = 0;
-            if ((int)lane == leader) slot = atomicAdd(&s_out, (uint32_t)__popcll(mask));
-            slot = __shfl(slot, leader);
-            if (keep) wf_store(q_out, seg_base + slot + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)), p);
-        }
+        __syncthreads();
+        count = s_out;  // survivors = the next bounce's paths
+        __syncthreads();
     }
-    __syncthreads();
-    if (threadIdx.x == 0) live_out[blockIdx.x] = s_out;
     stat_add(stats + kStatClosest, n_closest);
     stat_add(stats + kStatShadow, n_shadow);
 }
@@ -527,7 +533,7 @@ void free_wavefront(hpt_ctx* ctx) {
     ctx->live_slots = 0;
 }
 
-int ensure_wavefront(hpt_ctx* ctx, uint64_t paths, int max_depth, uint32_t segments) {
+int ensure_wavefront(hpt_ctx* ctx, uint64_t paths, uint32_t segments) {
     if (ctx->wf_allocated < paths) {
         for (auto& p : ctx->d_wf) {
             (void)hipFree(p);
@@ -537,7 +543,7 @@ int ensure_wavefront(hpt_ctx* ctx, uint64_t paths, int max_depth, uint32_t segme
         for (auto& p : ctx->d_wf) HIP_TRY(hipMalloc((void**)&p, paths * sizeof(float4)));
         ctx->wf_allocated = paths;
     }
-    const size_t want = (size_t)(max_depth + 1) * segments;  // one live counter per bounce and segment
+    const size_t want = segments;  // one live counter per segment (written by the generate kernel)
     if (ctx->live_slots < want) {
         (void)hipFree(ctx->d_live);
         ctx->d_live = nullptr;
@@ -1103,31 +1109,25 @@ int hpt_render(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sample
         // one queue segment per workgroup; exactly the workgroups that are resident at once
         int per_cu = 0;
         HPT_DISPATCH_SCENE(S.variant, {
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_bounce<kS>, wblock, lds_bytes(S, wblock)));
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_bounces<kS>, wblock, lds_bytes(S, wblock)));
         })
         if (per_cu < 1) return fail(HPT_ERR_INVALID_ARGUMENT, "the wavefront kernel does not fit a compute unit with %u bytes of LDS", lds_bytes(S, wblock));
         const uint64_t cap_groups = (cap + 63ull) >> 6;
         const uint32_t segments = (uint32_t)std::min<uint64_t>((uint64_t)per_cu * (uint64_t)ctx->num_cus, cap_groups);
         const uint32_t seg = (uint32_t)((cap_groups + segments - 1ull) / segments) * 64u;  // records per segment
-        if (int rc = ensure_wavefront(ctx, (uint64_t)seg * segments, max_depth, segments)) return rc;
+        if (int rc = ensure_wavefront(ctx, (uint64_t)seg * segments, segments)) return rc;
         WfQueue q[2] = {{ctx->d_wf[0], ctx->d_wf[1], ctx->d_wf[2], ctx->d_wf[3]}, {ctx->d_wf[4], ctx->d_wf[5], ctx->d_wf[6], ctx->d_wf[7]}};
         // the generate kernel needs whole waves
         const int gblock = (wblock + 63) & ~63;
         for (uint64_t first = 0; first < total; first += cap) {
             const uint32_t count = (uint32_t)((total - first < cap) ? total - first : cap);
-            HIP_TRY(hipMemsetAsync(ctx->d_live, 0, (size_t)(max_depth + 1) * segments * sizeof(uint32_t), stream));
             hipLaunchKernelGGL(k_wf_generate, dim3(segments), dim3(gblock), 0, stream, S, sample_begin, first, count, (uint32_t)lanes, seg, q[0], ctx->d_live, ctx->d_stats);
             HIP_TRY(hipGetLastError());
-            ++launches;
-            for (int it = 0; it < max_depth; ++it) {
-                const WfQueue& qi = q[it & 1];
-                const WfQueue& qo = q[(it + 1) & 1];
-                HPT_DISPATCH_SCENE(S.variant, {
-                    hipLaunchKernelGGL((k_wf_bounce<kS>), dim3(segments), dim3(wblock), lds_bytes(S, wblock), stream, S, max_depth, seg, qi, ctx->d_live + (size_t)it * segments, qo, ctx->d_live + (size_t)(it + 1) * segments, accum, ctx->d_stats);
-                })
-                HIP_TRY(hipGetLastError());
-                ++launches;
-            }
+            HPT_DISPATCH_SCENE(S.variant, {
+                hipLaunchKernelGGL((k_wf_bounces<kS>), dim3(segments), dim3(wblock), lds_bytes(S, wblock), stream, S, max_depth, seg, q[0], q[1], ctx->d_live, accum, ctx->d_stats);
+            })
+            HIP_TRY(hipGetLastError());
+            launches += 2;
         }
     }
     HIP_TRY(hipEventRecord(ev1, stream));
