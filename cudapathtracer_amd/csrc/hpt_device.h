@@ -298,7 +298,7 @@ HD void stage_scene(const DevScene& S, float4* lds) {
             lds[i] = v;
         }
         for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) lds[18u * nn + i] = S.tris[i];
-        if (threadIdx.x < 32u) reinterpret_cast<uint32_t*>(lds + 18u * nn + nt)[threadIdx.x] = S.oct_table[threadIdx.x];
+        for (uint32_t i = threadIdx.x; i < 32u; i += blockDim.x) reinterpret_cast<uint32_t*>(lds + 18u * nn + nt)[i] = S.oct_table[i];
         __syncthreads();
     }
 }

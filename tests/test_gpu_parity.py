@@ -172,6 +172,25 @@ def test_sample_chunks_and_spare_waves(hp, oracle, gpu_ctx):
         assert np.array_equal(got.view(np.int32), oracle.resolve(want_acc, spp).view(np.int32))
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_extreme_shapes(hp, oracle, gpu_ctx, mode):
+    """a one-pixel image with one lane per workgroup, a one-row image, depth 1, and a sample range
+    that ends at the top of the 32-bit sample index space."""
+    for (w, h, block, depth, s0, spp) in ((1, 1, 1, 3, 0, 5), (19, 1, 7, 1, 0, 3), (9, 10, 64, 4, 0xFFFFFFF0, 15)):
+        sc = hp.Scene.CreateBuiltinScene(hp.Scene.CornellBox, depth, w, h)
+        osc = oracle.cornell(w, h)
+        gpu_ctx.upload(sc)
+        gpu_ctx.accum_clear()
+        gpu_ctx.stats_reset()
+        gpu_ctx.render(mode, block, depth, s0, spp)
+        got = gpu_ctx.resolve(spp)
+        st = gpu_ctx.stats()
+        want_acc, ost = osc.render(RNG_PHILOX, TRIG_PORTABLE, depth, spp, sample_begin=s0, fixed=True)
+        assert (st["closest_queries"], st["shadow_queries"], st["paths"]) == \
+            (ost["closest_queries"], ost["shadow_queries"], ost["paths"]), (w, h, block)
+        assert np.array_equal(got.view(np.int32), oracle.resolve(want_acc, spp).view(np.int32)), (w, h, block)
+
+
 def test_cpp_hiprenderer_equals_c_abi(hp, oracle, gpu_ctx):
     """the C++ HipRenderer class (PrepareRender/Render/FinishRender) and the Python mirror."""
     w = h = 64
