@@ -96,6 +96,54 @@ def test_forced_variants(hp, oracle, gpu_ctx, monkeypatch, variant):
         assert np.array_equal(gpu_ctx.resolve(spp).view(np.int32), oracle.resolve(want_acc, spp).view(np.int32))
 
 
+def _soup(n, seed, size=200.0):
+    """n random triangles around the centre of the Cornell volume"""
+    rs = np.random.RandomState(seed)
+    c = rs.rand(n, 1, 3) * [400, 400, 400] + [78, 70, 80]
+    return (c + (rs.rand(n, 3, 3) - 0.5) * size).astype(np.float32)
+
+
+@pytest.mark.parametrize("name", ["one_triangle", "no_light", "degenerate", "soup33", "soup64", "soup65"])
+def test_small_custom_scenes(hp, oracle, gpu_ctx, name):
+    """edges of the scene description: a tree that is a single leaf, no emitter at all, zero-area
+    triangles (NaN normals), and triangle counts on both sides of the variant thresholds."""
+    from cudapathtracer_amd import scenes
+    light = dict(type=0, emission=scenes.light_emission())
+    quad = np.array([[[100, 500, 100], [400, 500, 100], [400, 500, 400]],
+                     [[100, 500, 100], [400, 500, 400], [100, 500, 400]]], np.float32)[:, ::-1]  # faces down
+    if name == "one_triangle":
+        parts = [("light", quad[:1], light)]
+    elif name == "no_light":
+        parts = [("a", _soup(5, 1), scenes.WHITE), ("b", _soup(3, 2), scenes.METAL)]
+    elif name == "degenerate":
+        t = _soup(6, 3)
+        t[1, 2] = t[1, 1]          # two equal vertices
+        t[4] = t[4, 0]             # a point
+        parts = [("light", quad, light), ("a", t, scenes.WHITE)]
+    else:
+        n = int(name[4:])
+        parts = [("light", quad, light), ("a", _soup(n - 2 - n // 3, 4), scenes.WHITE), ("b", _soup(n // 3, 5), scenes.METAL)]
+    w, h, depth, spp = 24, 16, 4, 3
+    sc = scenes._assemble(parts, w, h, depth)
+    osc = _oracle_scene(oracle, parts, w, h)
+    gpu_ctx.upload(sc)
+    nt = sum(len(p[1]) for p in parts)
+    assert gpu_ctx.stats()["variant"] == (2 if nt <= 32 else 3 if nt <= 64 else 6)
+    o, d = primary_rays(64, 64, scenes.CORNELL_CAM, osc.info()["cam_scale"])
+    _same_hits(gpu_ctx, osc, o, d)
+    _same_hits(gpu_ctx, osc, *random_rays(1 << 14, 61))
+    _same_hits(gpu_ctx, osc, *_shadow_batch(1 << 13, 62))
+    want_acc, ost = osc.render(RNG_PHILOX, TRIG_PORTABLE, depth, spp, fixed=True)
+    for mode in (1, 2):
+        gpu_ctx.stats_reset()
+        gpu_ctx.accum_clear()
+        gpu_ctx.render(mode, 64, depth, 0, spp)
+        got = gpu_ctx.resolve(spp)
+        st = gpu_ctx.stats()
+        assert (st["closest_queries"], st["shadow_queries"]) == (ost["closest_queries"], ost["shadow_queries"])
+        assert np.array_equal(got.view(np.int32), oracle.resolve(want_acc, spp).view(np.int32)), "mode %d" % mode
+
+
 def test_million_triangle_heightfield(hp, oracle, gpu_ctx):
     """~1.0 M triangles / 2.0 M nodes: topology equal to the oracle's, hits bit-exact."""
     from cudapathtracer_amd import scenes
