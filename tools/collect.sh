@@ -7,7 +7,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_mode1 -- python3 /root/repo/bench.py --no-cpu-baseline > $OUT/prof_mode1.log 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_mode2 -- python3 /root/repo/bench.py --no-cpu-baseline --mode 2 --steps 2 --warmup 1 --spp-per-step 16 > $OUT/prof_mode2.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_mode2 -- python3 /root/repo/bench.py --no-cpu-baseline --mode 2 --steps 4 --warmup 1 --spp-per-step 16 > $OUT/prof_mode2.log 2>&1 || exit 1
 cd $GRAFT_REPO_ROOT
 bash tools/pmc.sh ${TAG}_pmc > /dev/null 2>&1 || exit 1
 timeout -k 10 300 python bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
