@@ -69,11 +69,13 @@ __device__ __forceinline__ bool lane_to_pixel(const DevScene& S, uint32_t g, uin
     return x < (uint32_t)S.width && y < (uint32_t)S.height;
 }
 
-// counters: one atomic per wave (every lane adding to the same address would serialise in L2)
+// counters: one atomic per wave (every lane adding to the same address would serialise in L2).
+// The wave sum is taken bit by bit over ballots, so lanes that do not exist (last wave of a
+// workgroup size that is no multiple of 64) cannot contribute.  Called from wave-uniform code.
 __device__ __forceinline__ void stat_add(unsigned long long* slot, uint32_t v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    if ((threadIdx.x & 63u) == 0u && v) atomicAdd(slot, (unsigned long long)v);
+    unsigned long long sum = 0;
+    for (int b = 0; b < 32; ++b) sum += (unsigned long long)__popcll(__ballot((v >> b) & 1u)) << b;
+    if ((threadIdx.x & 63u) == 0u && sum) atomicAdd(slot, sum);
 }
 
 template <int kScene>
@@ -108,9 +110,9 @@ __device__ __forceinline__ void accumulate_pixel(int64_t* accum, uint32_t pixel,
     atomicAdd(a + 2, (unsigned long long)radiance_to_fixed(rad.z));
 }
 
-// Waves per SIMD the single-kernel variant is compiled for.  4 = 116 VGPRs, no spills.
-// 5 (96 VGPRs, 19 dwords spilled to scratch) measured 4 % faster on the Cornell workload but
-// turns 75 MB of HBM writes per launch into 15 GB of scratch traffic; 6 and 8 are slower.
+// Waves per SIMD the single-kernel variant is compiled for.  4 = 118 VGPRs, no spills.  The
+// kernel is VALU-issue bound: builds for 3 and for 5 waves (the latter spills to scratch) run
+// within 2 % of it.
 #ifndef HPT_MEGA_WAVES
 #define HPT_MEGA_WAVES 4
 #endif

@@ -1,7 +1,7 @@
 // Device-side building blocks of the gfx950 path-tracing core: vector math in
 // the reference's (glm) operation order, the keyed Philox stream, the portable
-// sin/cos/acos, the threaded BVH walk over the flattened node/triangle records
-// and one bounce of the MIS integrator.
+// sin/cos/acos, the BVH traversal variants over the flattened node/triangle
+// records and one bounce of the MIS integrator.
 //
 // Arithmetic contract: this translation unit is compiled with
 // -ffp-contract=off; every float/double operation below is a single IEEE-754
@@ -217,15 +217,15 @@ struct DevScene {
     uint32_t seed;
     uint32_t lds_float4s;  // > 0: that many float4 of node (or pair) + triangle records are staged into LDS
     int32_t variant;       // kSceneGlobal .. kScenePairLds
-    // two-child records of the same tree (variants kScenePair / kScenePairLds), 4 x float4 per
-    // interior node, in pre-order:
-    //   (left.pMin, left ref) (left.pMax, right ref) (right.pMin, -) (right.pMax, -)
-    // ref >= 0: index of the child's own record; ref < 0: the child is a leaf, triangle ~ref
     // marking variants: nine pre-processed copies of the node array (see stage_scene) and their
     // table: dword k = nodes in copy k, dwords 16 + 2k / 17 + 2k = triangles whose back-face test
     // is still needed for a ray of sign octant k
     const float4* oct_nodes;
     const uint32_t* oct_table;
+    // two-child records of the same tree (variants kScenePair / kScenePairLds), 4 x float4 per
+    // interior node, in pre-order:
+    //   (left.pMin, left ref) (left.pMax, right ref) (right.pMin, -) (right.pMax, -)
+    // ref >= 0: index of the child's own record; ref < 0: the child is a leaf, triangle ~ref
     const float4* pairs;
     uint32_t num_pairs;
     uint32_t stack_depth;  // entries of the per-lane traversal stack that no ray can exceed
@@ -233,10 +233,6 @@ struct DevScene {
     unsigned long long* prof;  // diagnostic builds only (3 x kProfSections totals), else null
 };
 
-// Stage the scene records a variant reads from LDS (tiny scenes: the Cornell box is
-// 63 nodes + 32 triangles = 4 KiB).  Every thread of the workgroup must call it.
-template <int kScene>
-HD void stage_scene(const DevScene& S, float4* lds);
 // ------------------------------------------------------------ traversal -----
 // Scene residency / traversal variant, chosen at upload from the scene size:
 enum {
@@ -262,10 +258,12 @@ HD float4 lds_read(uint32_t at) {
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
+// Stage the records a variant reads from LDS (the Cornell box: 20 KiB).  Every thread of the
+// workgroup must call it; it ends with a workgroup barrier (also for the variants that stage nothing).
 template <int kScene>
 HD void stage_scene(const DevScene& S, float4* lds) {
     if constexpr (kScene == kSceneGlobal || kScene == kScenePair) {
-        return;
+        __syncthreads();
     } else if constexpr (kScene == kScenePairLds) {
         const uint32_t np = 4u * S.num_pairs, nt = 4u * S.num_tris;
         for (uint32_t i = threadIdx.x; i < np; i += blockDim.x) lds[i] = S.pairs[i];
@@ -366,8 +364,9 @@ HD bool tri_hit(const float4* __restrict__ T, int tri, f3 o, f3 d, double& t_out
 // kShadow: any-hit with t < tmax - Epsilon4 (BVH.hpp:121-127).  Which triangles
 // are tested is decided by the box tests alone, so deferring the tests changes
 // no result; an occluded shadow ray merely finishes its box walk first.
-// Per-lane queue of leaf triangles whose test is still to be run (variants
-// kSceneGlobal / kSceneLds): kTriQueue entries in LDS, entry k of a lane at q[k * stride].
+
+// Per-lane queue of leaf triangles whose test is still to be run (all variants but the marking
+// ones): kTriQueue entries in LDS, entry k of a lane at q[k * stride].
 constexpr uint32_t kTriQueue = 8;
 struct TriQueue {
     uint32_t* q;
