@@ -115,6 +115,7 @@ def _declare(L, H):
     L.hpt_accum_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     H.hpt_host_last_error.restype = C.c_char_p
     H.hpt_host_scene_cornell.argtypes = [C.c_char_p, i32, i32, i32, C.POINTER(vp)]
+    H.hpt_host_scene_builtin.argtypes = [i32, C.c_char_p, i32, i32, i32, C.POINTER(vp)]
     H.hpt_host_scene_create.argtypes = [i32, i32, vp, C.c_double, i32, C.POINTER(vp)]
     H.hpt_host_scene_add_obj.argtypes = [vp, C.c_char_p, C.POINTER(hpt_material)]
     H.hpt_host_scene_add_triangles.argtypes = [vp, vp, i32, C.POINTER(hpt_material)]
@@ -162,6 +163,7 @@ class Scene:
     and its flattened form."""
 
     CornellBox = 0
+    BunnyInCornell = 1   # Cornell walls + light with the Stanford bunny in place of the boxes (not in the reference)
 
     def __init__(self, width, height, camPos=(0.0, 0.0, 0.0), fov=40.0, maxDepth=1, _handle=None):
         self._H = load_libraries()[1]
@@ -179,13 +181,13 @@ class Scene:
     @staticmethod
     def CreateBuiltinScene(sceneId=0, maxDepth=10, width=0, height=0, models_dir=DEFAULT_MODELS_DIR):
         """Scene::CreateBuiltinScene (common/Scene.cpp:25-73); 512x512 unless a resolution is given."""
-        if sceneId != Scene.CornellBox:
+        if sceneId not in (Scene.CornellBox, Scene.BunnyInCornell):
             raise HptError("Unsupported sceneId")
         H = load_libraries()[1]
         h = C.c_void_p()
-        _ckh(H.hpt_host_scene_cornell(models_dir.encode(), int(width), int(height), int(maxDepth), C.byref(h)))
+        _ckh(H.hpt_host_scene_builtin(int(sceneId), models_dir.encode(), int(width), int(height), int(maxDepth), C.byref(h)))
         s = Scene(width or 512, height or 512, maxDepth=maxDepth, _handle=h)
-        s.name = "Cornell Box"
+        s.name = "Cornell Box" if sceneId == Scene.CornellBox else "Bunny"
         s._built = True
         return s
 

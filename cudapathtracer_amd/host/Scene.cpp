@@ -1,8 +1,11 @@
 #include "Scene.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
+#include <string>
+#include <vector>
 
 void AlignedFloats::resize(size_t n) {
     storage.assign(n + 16, 0.f);
@@ -177,6 +180,7 @@ hpt_scene_desc Scene::describe() const {
 // The built-in Cornell box: resolution, camera, materials, mesh order and
 // file names of common/Scene.cpp:25-73.
 Scene Scene::CreateBuiltinScene(Scene::BuiltinScene sceneId, int maxDepth) {
+    if (sceneId == Scene::BuiltinScene::BunnyInCornell) return CreateBunnyScene(maxDepth);
     if (sceneId != Scene::BuiltinScene::CornellBox) throw std::runtime_error("Unsupported sceneId");
     Scene scene(512, 512);
     scene.name = "Cornell Box";
@@ -205,6 +209,46 @@ Scene Scene::CreateBuiltinScene(Scene::BuiltinScene sceneId, int maxDepth) {
     scene.Add(new MeshTriangle(dir + "left.obj", red));
     scene.Add(new MeshTriangle(dir + "right.obj", green));
     scene.Add(new MeshTriangle(dir + "light.obj", light));
+    scene.buildBVH();
+    return scene;
+}
+
+// Cornell shell (floor incl. ceiling and back wall, left, right, light) + the bunny.  The OBJ's
+// vertices are scaled by 2000 and moved so that the bounding box is centred at (x, z) =
+// (278, 280) and its bottom lies on y = 0; all in float, one operation at a time, so that the
+// vertices equal those of cudapathtracer_amd/scenes.py (bunny_triangles) bit for bit.
+Scene Scene::CreateBunnyScene(int maxDepth) {
+    Scene scene(512, 512);
+    scene.name = "Bunny";
+    scene.maxDepth = maxDepth;
+    scene.camPos = Vec3(278, 273, -800);
+
+    Material red, green, white, light;
+    red._albedo = Vec3(0.63f, 0.065f, 0.05f);
+    green._albedo = Vec3(0.14f, 0.45f, 0.091f);
+    white._albedo = Vec3(0.725f, 0.71f, 0.68f);
+    light._emission = (8.0f * Vec3(0.747f + 0.058f, 0.747f + 0.258f, 0.747f) + 15.6f * Vec3(0.740f + 0.287f, 0.740f + 0.160f, 0.740f) +
+                       18.4f * Vec3(0.737f + 0.642f, 0.737f + 0.159f, 0.737f));
+
+    const char* env = std::getenv("HPT_MODELS_DIR");
+    const std::string root = std::string(env && *env ? env : "models");
+    scene.Add(new MeshTriangle(root + "/cornellbox/floor.obj", white));
+    scene.Add(new MeshTriangle(root + "/cornellbox/left.obj", red));
+    scene.Add(new MeshTriangle(root + "/cornellbox/right.obj", green));
+    scene.Add(new MeshTriangle(root + "/cornellbox/light.obj", light));
+
+    MeshTriangle raw(root + "/bunny/bunny.obj", white);
+    Vec3 lo = raw.vertices.at(0), hi = lo;
+    for (const Vec3& v : raw.vertices) {
+        lo = Vec3(std::min(lo.x, v.x), std::min(lo.y, v.y), std::min(lo.z, v.z));
+        hi = Vec3(std::max(hi.x, v.x), std::max(hi.y, v.y), std::max(hi.z, v.z));
+    }
+    const float s = 2000.0f;
+    const Vec3 off(278.0f - s * (lo.x + hi.x) * 0.5f, -s * lo.y, 280.0f - s * (lo.z + hi.z) * 0.5f);
+    std::vector<Vec3> moved;
+    moved.reserve(raw.vertices.size());
+    for (const Vec3& v : raw.vertices) moved.push_back(Vec3(v.x * s + off.x, v.y * s + off.y, v.z * s + off.z));
+    scene.Add(new MeshTriangle(moved, white));
     scene.buildBVH();
     return scene;
 }

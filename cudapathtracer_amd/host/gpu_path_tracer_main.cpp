@@ -11,6 +11,7 @@
 //   HPT_DEVICE               GPU index (default 0)
 #include <cstdlib>
 #include <iostream>
+#include <string>
 
 #include "HipRenderer.hpp"
 #include "Scene.hpp"
@@ -27,7 +28,9 @@ int main(int argc, char** argv) {
     if (argc > 4) mode = (HipRenderMode)atoi(argv[4]);
 
     try {
-        Scene scene = Scene::CreateBuiltinScene(Scene::CornellBox, maxDepth);
+        // HPT_SCENE=bunny renders the bunny scene instead of the reference's only scene
+        const char* which = getenv("HPT_SCENE");
+        Scene scene = Scene::CreateBuiltinScene(which && std::string(which) == "bunny" ? Scene::BunnyInCornell : Scene::CornellBox, maxDepth);
         if (const char* w = getenv("HPT_WIDTH")) scene.width = atoi(w);
         if (const char* h = getenv("HPT_HEIGHT")) scene.height = atoi(h);
 

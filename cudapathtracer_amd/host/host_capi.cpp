@@ -62,6 +62,19 @@ int hpt_host_scene_cornell(const char* models_dir, int width, int height, int ma
     })
 }
 
+int hpt_host_scene_builtin(int scene_id, const char* models_dir, int width, int height, int max_depth, hpt_host_scene** out) {
+    if (!out) return fail("out is null");
+    *out = nullptr;
+    if (scene_id != (int)Scene::CornellBox && scene_id != (int)Scene::BunnyInCornell) return fail("unknown built-in scene");
+    GUARD({
+        if (models_dir) setenv("HPT_MODELS_DIR", models_dir, 1);
+        Scene sc = Scene::CreateBuiltinScene((Scene::BuiltinScene)scene_id, max_depth);
+        if (width > 0) sc.width = width;
+        if (height > 0) sc.height = height;
+        *out = new hpt_host_scene(sc);
+    })
+}
+
 int hpt_host_scene_create(int width, int height, const float cam_pos[3], double fov_deg, int max_depth, hpt_host_scene** out) {
     if (!out || !cam_pos) return fail("null argument");
     *out = nullptr;

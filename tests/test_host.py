@@ -188,6 +188,18 @@ def test_custom_scene_and_bunny_topology(hp, oracle):
     assert len(f["lights"]) == 1 and f["lights"][0][3] == 1
 
 
+def test_builtin_bunny_scene_equals_the_python_definition(hp):
+    """Scene::CreateBuiltinScene(BunnyInCornell) (C++: OBJ reader + float transform) and
+    scenes.bunny_in_cornell (numpy) flatten to the same arrays, bit for bit."""
+    from cudapathtracer_amd import scenes
+    a = hp.Scene.CreateBuiltinScene(hp.Scene.BunnyInCornell, 7, 64, 48).flat_arrays()
+    b = scenes.bunny_in_cornell(64, 48, 7).flat_arrays()
+    assert a["tris"].shape == (4980, 16)
+    for k in ("nodes", "tris", "tri_v12", "node_area"):
+        assert np.array_equal(np.asarray(a[k]).view(np.uint32), np.asarray(b[k]).view(np.uint32)), k
+    assert a["cam_scale"] == b["cam_scale"]
+
+
 def test_scene_errors(hp, tmp_path):
     with pytest.raises(hp.HptError):
         hp.Scene.CreateBuiltinScene(hp.Scene.CornellBox, 5, models_dir=str(tmp_path))
@@ -203,7 +215,7 @@ def test_scene_errors(hp, tmp_path):
     with pytest.raises(hp.HptError):
         sc.describe()          # not built
     with pytest.raises(hp.HptError):
-        hp.Scene.CreateBuiltinScene(1, 5)
+        hp.Scene.CreateBuiltinScene(2, 5)   # 0 Cornell box, 1 bunny; nothing else
 
 
 def test_save_ppm_tone_curve(hp, tmp_path):
