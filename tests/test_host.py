@@ -42,6 +42,18 @@ def test_libraries_export_every_declared_symbol(hp):
     assert "gfx950" in out or out.strip() == ""
 
 
+def test_headers_are_plain_c(tmp_path):
+    """the boundary is a C ABI: both headers compile as C99 on their own"""
+    import shutil
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    src = tmp_path / "abi.c"
+    src.write_text('#include "hpt.h"\n#include "hpt_host.h"\nint main(void) { hpt_stats s; hpt_scene_desc d; (void)s; (void)d; return 0; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                        "-fsyntax-only", str(src)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+
+
 def test_host_bvh_equals_reference_fixture(cornell):
     g = np.load(os.path.join(G, "cornell_bvh.npz"))
     for mesh in range(-1, 6):
