@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import cudapathtracer_amd as hp
-from orclib import primary_rays, random_rays, shadow_rays
+from raybatches import primary_rays, random_rays, shadow_rays
 
 sc = hp.Scene.CreateBuiltinScene(0, 20, 1024, 1024)
 ctx = hp.Context(0).upload(sc)

@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import cudapathtracer_amd as hp
 from cudapathtracer_amd import scenes
-from orclib import random_rays
+from raybatches import random_rays
 
 n = 1 << 22
 o, d = random_rays(n, 1)
