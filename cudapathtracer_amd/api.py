@@ -127,6 +127,7 @@ def _declare(L, H):
     H.hpt_host_bvh_dump.argtypes = [vp, i32, C.POINTER(C.c_int), vp, vp, vp, vp]
     H.hpt_host_render.argtypes = [vp, i32, i32, i32, i32, i32, vp, C.POINTER(hpt_stats)]
     H.hpt_host_save_ppm.argtypes = [C.c_char_p, vp, i32, i32]
+    H.hpt_host_save_pfm.argtypes = [C.c_char_p, vp, i32, i32]
 
 
 def _ck(rc):
@@ -387,6 +388,12 @@ def SavePPM(path, framebuffer, width, height):
     """Utility::SavePPM (common/Utility.cpp:4-22)."""
     rgb = np.ascontiguousarray(framebuffer, np.float32)
     _ckh(load_libraries()[1].hpt_host_save_ppm(os.fspath(path).encode(), rgb.ctypes.data, int(width), int(height)))
+
+
+def SavePFM(path, framebuffer, width, height):
+    """Utility::SavePFM: linear float RGB as a portable float map (not in the reference)."""
+    rgb = np.ascontiguousarray(framebuffer, np.float32)
+    _ckh(load_libraries()[1].hpt_host_save_pfm(os.fspath(path).encode(), rgb.ctypes.data, int(width), int(height)))
 
 
 def device_count():

@@ -32,6 +32,14 @@ void Utility::SavePPM(const std::string& path, const std::vector<Vec3>& frameBuf
     std::fclose(fp);
 }
 
+void Utility::SavePFM(const std::string& path, const std::vector<Vec3>& frameBuffer, int width, int height) {
+    FILE* fp = std::fopen(path.c_str(), "wb");
+    if (!fp) throw std::runtime_error("Failed to open file '" + path + "'. Error: " + std::strerror(errno));
+    std::fprintf(fp, "PF\n%d %d\n-1.0\n", width, height);  // negative scale = little-endian floats
+    for (int y = height - 1; y >= 0; --y) std::fwrite(&frameBuffer[(size_t)y * width], sizeof(Vec3), (size_t)width, fp);
+    std::fclose(fp);
+}
+
 void Utility::UpdateProgress(float progress) {
     const int barWidth = 70;
     const int pos = (int)(barWidth * progress);

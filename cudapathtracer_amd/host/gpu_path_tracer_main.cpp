@@ -57,6 +57,7 @@ int main(int argc, char** argv) {
                       << " spp/s)\n";
 
         Utility::SavePPM("out/gpu/" + scene.name + ".ppm", r.framebuffer, scene.width, scene.height);
+        if (getenv("HPT_PFM")) Utility::SavePFM("out/gpu/" + scene.name + ".pfm", r.framebuffer, scene.width, scene.height);
     } catch (const std::exception& e) {
         std::cerr << "gpu_path_tracer: " << e.what() << std::endl;
         return 1;

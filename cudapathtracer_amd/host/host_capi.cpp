@@ -191,4 +191,13 @@ int hpt_host_save_ppm(const char* path, const float* rgb, int width, int height)
     })
 }
 
+int hpt_host_save_pfm(const char* path, const float* rgb, int width, int height) {
+    if (!path || !rgb || width <= 0 || height <= 0) return fail("bad argument");
+    GUARD({
+        std::vector<Vec3> fb((size_t)width * height);
+        std::memcpy(static_cast<void*>(fb.data()), rgb, fb.size() * sizeof(Vec3));
+        Utility::SavePFM(path, fb, width, height);
+    })
+}
+
 }  // extern "C"

@@ -54,6 +54,8 @@ int hpt_host_render(const hpt_host_scene* s, int device, int spp, int max_depth,
                     hpt_stats* stats);
 /* Utility::SavePPM (common/Utility.cpp:4-22) */
 int hpt_host_save_ppm(const char* path, const float* rgb, int width, int height);
+/* Utility::SavePFM: linear float RGB as a portable float map (no counterpart in the reference) */
+int hpt_host_save_pfm(const char* path, const float* rgb, int width, int height);
 
 #ifdef __cplusplus
 }

@@ -246,5 +246,17 @@ def test_save_ppm_tone_curve(hp, tmp_path):
         hp.SavePPM(str(tmp_path / "no_such_dir" / "x.ppm"), fb, n, 1)
 
 
+def test_save_pfm_round_trip(hp, tmp_path):
+    w, h = 5, 3
+    fb = np.random.RandomState(3).rand(h * w, 3).astype(np.float32) * 40 - 1
+    path = tmp_path / "x.pfm"
+    hp.SavePFM(path, fb, w, h)
+    raw = path.read_bytes()
+    head = b"PF\n5 3\n-1.0\n"
+    assert raw.startswith(head) and len(raw) == len(head) + w * h * 12
+    got = np.frombuffer(raw[len(head):], "<f4").reshape(h, w, 3)[::-1]   # rows are stored bottom to top
+    assert np.array_equal(got.reshape(-1, 3), fb)
+
+
 def test_cli_is_built():
     assert os.access(os.path.join(ROOT, "build", "gpu_path_tracer"), os.X_OK)
