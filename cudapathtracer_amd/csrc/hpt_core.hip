@@ -378,7 +378,7 @@ __global__ void __launch_bounds__(256)
 k_wf_bounces(DevScene S, int max_depth, uint32_t seg, WfQueue q0, WfQueue q1, const uint32_t* __restrict__ live,
              int64_t* __restrict__ accum, unsigned long long* __restrict__ stats) {
     extern __shared__ float4 lds[];
-    __shared__ uint32_t s_out;
+    __shared__ uint32_t s_out, s_next;
     uint32_t count = live[blockIdx.x];
     if (count == 0) return;
     stage_scene<kScene>(S, lds);
@@ -391,15 +391,21 @@ k_wf_bounces(DevScene S, int max_depth, uint32_t seg, WfQueue q0, WfQueue q1, co
     ProfAcc prof;
     prof.w = prof_dummy;
 #endif
-    // all lanes of a wave run the same number of iterations so that the ballot below always
-    // sees the whole wave
-    const uint32_t wave_first = threadIdx.x - lane;
+    const uint32_t wave_lanes = min(64u, blockDim.x - (threadIdx.x - lane));  // the last wave of an odd-sized workgroup is partial
     for (int bounce = 0; bounce < max_depth && count; ++bounce) {
         const WfQueue& q_in = (bounce & 1) ? q1 : q0;
         const WfQueue& q_out = (bounce & 1) ? q0 : q1;
-        if (threadIdx.x == 0) s_out = 0;
+        if (threadIdx.x == 0) {
+            s_out = 0;
+            s_next = 0;
+        }
         __syncthreads();  // also: the records the previous bounce stored are visible to the whole workgroup
-        for (uint32_t base = wave_first; base < count; base += blockDim.x) {
+        // waves take groups of records (one per lane) as they become free: their traversal times differ
+        for (;;) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&s_next, wave_lanes);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (base >= count) break;
             const uint32_t i = base + lane;
             const WfRecord cur = wf_fetch(q_in, seg_base, i, count);
             bool keep = false;
