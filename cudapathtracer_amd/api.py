@@ -165,6 +165,7 @@ class Scene:
 
     CornellBox = 0
     BunnyInCornell = 1   # Cornell walls + light with the Stanford bunny in place of the boxes (not in the reference)
+    GlassCornell = 2     # CornellBox with the short box switched to Material::Type::Glass (roughness 0.2, ior 1.5)
 
     def __init__(self, width, height, camPos=(0.0, 0.0, 0.0), fov=40.0, maxDepth=1, _handle=None):
         self._H = load_libraries()[1]
@@ -182,13 +183,13 @@ class Scene:
     @staticmethod
     def CreateBuiltinScene(sceneId=0, maxDepth=10, width=0, height=0, models_dir=DEFAULT_MODELS_DIR):
         """Scene::CreateBuiltinScene (common/Scene.cpp:25-73); 512x512 unless a resolution is given."""
-        if sceneId not in (Scene.CornellBox, Scene.BunnyInCornell):
+        if sceneId not in (Scene.CornellBox, Scene.BunnyInCornell, Scene.GlassCornell):
             raise HptError("Unsupported sceneId")
         H = load_libraries()[1]
         h = C.c_void_p()
         _ckh(H.hpt_host_scene_builtin(int(sceneId), models_dir.encode(), int(width), int(height), int(maxDepth), C.byref(h)))
         s = Scene(width or 512, height or 512, maxDepth=maxDepth, _handle=h)
-        s.name = "Cornell Box" if sceneId == Scene.CornellBox else "Bunny"
+        s.name = ("Cornell Box", "Bunny", "Glass Cornell")[sceneId]
         s._built = True
         return s
 
@@ -227,6 +228,8 @@ class Scene:
             tris=np.ctypeslib.as_array(d.tris, (nt, 16)).copy(),
             tri_v12=np.ctypeslib.as_array(d.tri_v12, (nt, 8)).copy(),
             prim_of_tri=prim,
+            materials=np.array([(m.type,) + tuple(m.emission) + tuple(m.albedo) + (m.metallic, m.roughness, m.ior)
+                                for m in (d.materials[i] for i in range(d.num_materials))], np.float32),
             lights=[(L.area, L.root_area, L.root_node, L.material) for L in (d.lights[i] for i in range(d.num_lights))],
             sum_light_area=d.sum_light_area, sum_light_power=d.sum_light_power, cam_scale=d.cam_scale,
             cam_pos=tuple(d.cam_pos), width=d.width, height=d.height)

@@ -126,7 +126,7 @@ __device__ __forceinline__ void accumulate_pixel(int64_t* accum, uint32_t pixel,
 // (any lane may finish any pixel of its tile); a unit's accumulator is added to the global
 // buffer when its last path has ended.  Units are numbered chunk-major, so the chunks of an
 // expensive tile are spread over the launch.
-template <int kScene, int kMaxBlock>
+template <int kScene, bool kGlass, int kMaxBlock>
 __global__ void __launch_bounds__(kMaxBlock, (kMaxBlock == 256 ? HPT_MEGA_WAVES : 1))
 k_render_mega(DevScene S, int max_depth, uint32_t s_begin_all, uint32_t s_count_all, uint32_t s_chunk, uint32_t n_units,
               int64_t* __restrict__ accum, unsigned long long* __restrict__ stats, uint32_t* __restrict__ unit_counter) {
@@ -250,7 +250,7 @@ k_render_mega(DevScene S, int max_depth, uint32_t s_begin_all, uint32_t s_count_
             double t;
             ++n_rays;
             trace<kScene, false>(S, lds, tq, p.o, p.d, 0.0, tri, t PROF_PASS);
-            alive = shade_bounce<kScene, 0x10000u>(S, lds, tq, p, tri, t, n_rays PROF_PASS) && p.depth < max_depth;
+            alive = shade_bounce<kScene, kGlass, 0x10000u>(S, lds, tq, p, tri, t, n_rays PROF_PASS) && p.depth < max_depth;
             if (!alive) {
                 unsigned long long* acc = tile_acc + lane_gen * 192u + 3u * slot;
                 atomicAdd(acc + 0u, (unsigned long long)radiance_to_fixed(p.rad.x));
@@ -373,7 +373,7 @@ __global__ void k_wf_generate(DevScene S, uint32_t s_begin, uint64_t first, uint
 // (int64 atomics).  Survivors are compacted with __ballot + prefix popcount and one LDS atomic
 // per wave.  Segments are independent, so the bounce loop runs inside the kernel with workgroup
 // barriers only: one launch per batch, the scene staged once, no workgroup waits for another.
-template <int kScene>
+template <int kScene, bool kGlass>
 __global__ void __launch_bounds__(256)
 k_wf_bounces(DevScene S, int max_depth, uint32_t seg, WfQueue q0, WfQueue q1, const uint32_t* __restrict__ live,
              int64_t* __restrict__ accum, unsigned long long* __restrict__ stats) {
@@ -417,7 +417,7 @@ k_wf_bounces(DevScene S, int max_depth, uint32_t seg, WfQueue q0, WfQueue q1, co
                     double t;
                     ++n_closest;
                     trace<kScene, false>(S, lds, tq, p.o, p.d, 0.0, tri, t PROF_PASS);
-                    keep = shade_bounce<kScene>(S, lds, tq, p, tri, t, n_shadow PROF_PASS) && p.depth < max_depth;
+                    keep = shade_bounce<kScene, kGlass>(S, lds, tq, p, tri, t, n_shadow PROF_PASS) && p.depth < max_depth;
                     if (!keep) accumulate_pixel(accum, p.pixel, p.rad);
                 }
             }
@@ -447,14 +447,23 @@ __global__ void k_resolve(const int64_t* __restrict__ accum, size_t n, double de
 }  // namespace
 
 // run CALL with kS bound to the scene's traversal variant as a compile-time constant
-#define HPT_DISPATCH_SCENE(variant, CALL)                                         \
-    switch (variant) {                                                            \
-    case kSceneGlobal: { constexpr int kS = kSceneGlobal; CALL; } break;          \
-    case kSceneLds: { constexpr int kS = kSceneLds; CALL; } break;                \
-    case kSceneTiny32: { constexpr int kS = kSceneTiny32; CALL; } break;          \
-    case kSceneTiny64: { constexpr int kS = kSceneTiny64; CALL; } break;          \
-    case kScenePair: { constexpr int kS = kScenePair; CALL; } break;              \
-    default: { constexpr int kS = kScenePairLds; CALL; } break;                   \
+#define HPT_DISPATCH_SCENE(variant, ...)                                                 \
+    switch (variant) {                                                                   \
+    case kSceneGlobal: { constexpr int kS = kSceneGlobal; __VA_ARGS__; } break;          \
+    case kSceneLds: { constexpr int kS = kSceneLds; __VA_ARGS__; } break;                \
+    case kSceneTiny32: { constexpr int kS = kSceneTiny32; __VA_ARGS__; } break;          \
+    case kSceneTiny64: { constexpr int kS = kSceneTiny64; __VA_ARGS__; } break;          \
+    case kScenePair: { constexpr int kS = kScenePair; __VA_ARGS__; } break;              \
+    default: { constexpr int kS = kScenePairLds; __VA_ARGS__; } break;                   \
+    }
+// the same with kG = "the scene has a Glass material" for the kernels that shade
+#define HPT_DISPATCH_RENDER(variant, glass, ...)                                         \
+    if (glass) {                                                                         \
+        constexpr bool kG = true;                                                        \
+        HPT_DISPATCH_SCENE(variant, __VA_ARGS__)                                         \
+    } else {                                                                             \
+        constexpr bool kG = false;                                                       \
+        HPT_DISPATCH_SCENE(variant, __VA_ARGS__)                                         \
     }
 
 // ------------------------------------------------------------------ context --
@@ -463,6 +472,7 @@ struct hpt_ctx {
     int device = 0;
     int num_cus = 256;
     bool has_scene = false;
+    bool has_glass = false;  // some material is Material::Type::Glass: selects the kernels that carry its branch
     DevScene S{};
     // scene arrays (device)
     float4* d_nodes = nullptr;
@@ -574,8 +584,8 @@ int validate_scene(const hpt_scene_desc* sc) {
     if (sc->num_materials == 0 || !sc->materials) return fail(HPT_ERR_INVALID_ARGUMENT, "scene has no materials");
     if (sc->num_lights && !sc->lights) return fail(HPT_ERR_INVALID_ARGUMENT, "lights pointer is null");
     for (uint32_t m = 0; m < sc->num_materials; ++m)
-        if (sc->materials[m].type < 0 || sc->materials[m].type > 1)
-            return fail(HPT_ERR_INVALID_ARGUMENT, "material %u: type %d is not traced on the device (0 Lambertian, 1 MetallicWorkflow)", m,
+        if (sc->materials[m].type < 0 || sc->materials[m].type > 2)
+            return fail(HPT_ERR_INVALID_ARGUMENT, "material %u: type %d is none of 0 Lambertian, 1 MetallicWorkflow, 2 Glass", m,
                         sc->materials[m].type);
     const int32_t nn = (int32_t)sc->num_nodes;
     std::vector<uint8_t> tri_seen(sc->num_tris, 0);
@@ -857,6 +867,7 @@ int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* sc) {
             return tx + ty + tz;
         };
         std::vector<DevMaterial> mats(sc->num_materials);
+        bool glass = false;
         for (uint32_t i = 0; i < sc->num_materials; ++i) {
             const hpt_material& m = sc->materials[i];
             DevMaterial& d = mats[i];
@@ -876,6 +887,8 @@ int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* sc) {
             d.roughness = m.roughness;
             d.rsq = m.roughness * m.roughness;
             d.rsq_minus_1 = d.rsq - 1.0f;
+            d.ior = m.ior;
+            if (m.type == 2) glass = true;
         }
         std::vector<DevLight> lights(sc->num_lights ? sc->num_lights : 1);
         std::memset(lights.data(), 0, lights.size() * sizeof(DevLight));
@@ -898,6 +911,7 @@ int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* sc) {
         }
         HIP_TRY(hipMemcpy(ctx->d_tris, tris.data(), nt * 64, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(ctx->d_mats, mats.data(), mats.size() * sizeof(DevMaterial), hipMemcpyHostToDevice));
+        ctx->has_glass = glass;
         HIP_TRY(hipMemcpy(ctx->d_lights, lights.data(), lights.size() * sizeof(DevLight), hipMemcpyHostToDevice));
     }
     // Two-child records of the same tree (see DevScene::pairs).  Interior node i has the children
@@ -1085,13 +1099,13 @@ int hpt_render(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sample
         if (lds_mega > kMaxLdsPerBlock)
             return fail(HPT_ERR_INVALID_ARGUMENT, "a workgroup of %d lanes needs %u bytes of LDS for this scene (limit %u): use a smaller block", block, lds_mega, kMaxLdsPerBlock);
         int per_cu = 0;
-        HPT_DISPATCH_SCENE(S.variant, {
+        HPT_DISPATCH_RENDER(S.variant, ctx->has_glass, {
             if (block <= 256) {
-                if (lds_mega > 48u * 1024u) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render_mega<kS, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mega));
-                HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_mega<kS, 256>, block, lds_mega));
+                if (lds_mega > 48u * 1024u) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render_mega<kS, kG, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mega));
+                HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_mega<kS, kG, 256>, block, lds_mega));
             } else {
-                if (lds_mega > 48u * 1024u) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render_mega<kS, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mega));
-                HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_mega<kS, 1024>, block, lds_mega));
+                if (lds_mega > 48u * 1024u) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render_mega<kS, kG, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mega));
+                HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_mega<kS, kG, 1024>, block, lds_mega));
             }
         })
         if (per_cu < 1) return fail(HPT_ERR_INVALID_ARGUMENT, "a workgroup of %d lanes with %u bytes of LDS does not fit a compute unit", block, lds_mega);
@@ -1101,9 +1115,9 @@ int hpt_render(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sample
             const uint32_t units = tiles * ((n + chunk - 1u) / chunk);
             const uint32_t blocks = std::min(resident, (units + waves_per_block - 1u) / waves_per_block);
             HIP_TRY(hipMemsetAsync(ctx->d_unit_counter, 0, sizeof(uint32_t), stream));
-            HPT_DISPATCH_SCENE(S.variant, {
-                if (block <= 256) hipLaunchKernelGGL((k_render_mega<kS, 256>), dim3(blocks), dim3(block), lds_mega, stream, S, max_depth, s, n, chunk, units, accum, ctx->d_stats, ctx->d_unit_counter);
-                else hipLaunchKernelGGL((k_render_mega<kS, 1024>), dim3(blocks), dim3(block), lds_mega, stream, S, max_depth, s, n, chunk, units, accum, ctx->d_stats, ctx->d_unit_counter);
+            HPT_DISPATCH_RENDER(S.variant, ctx->has_glass, {
+                if (block <= 256) hipLaunchKernelGGL((k_render_mega<kS, kG, 256>), dim3(blocks), dim3(block), lds_mega, stream, S, max_depth, s, n, chunk, units, accum, ctx->d_stats, ctx->d_unit_counter);
+                else hipLaunchKernelGGL((k_render_mega<kS, kG, 1024>), dim3(blocks), dim3(block), lds_mega, stream, S, max_depth, s, n, chunk, units, accum, ctx->d_stats, ctx->d_unit_counter);
             })
             HIP_TRY(hipGetLastError());
             ++launches;
@@ -1116,8 +1130,8 @@ int hpt_render(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sample
         const uint64_t cap = ctx->wf_capacity < total ? ctx->wf_capacity : ((total + 63ull) & ~63ull);
         // one queue segment per workgroup; exactly the workgroups that are resident at once
         int per_cu = 0;
-        HPT_DISPATCH_SCENE(S.variant, {
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_bounces<kS>, wblock, lds_bytes(S, wblock)));
+        HPT_DISPATCH_RENDER(S.variant, ctx->has_glass, {
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_bounces<kS, kG>, wblock, lds_bytes(S, wblock)));
         })
         if (per_cu < 1) return fail(HPT_ERR_INVALID_ARGUMENT, "the wavefront kernel does not fit a compute unit with %u bytes of LDS", lds_bytes(S, wblock));
         const uint64_t cap_groups = (cap + 63ull) >> 6;
@@ -1131,8 +1145,8 @@ int hpt_render(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sample
             const uint32_t count = (uint32_t)((total - first < cap) ? total - first : cap);
             hipLaunchKernelGGL(k_wf_generate, dim3(segments), dim3(gblock), 0, stream, S, sample_begin, first, count, (uint32_t)lanes, seg, q[0], ctx->d_live, ctx->d_stats);
             HIP_TRY(hipGetLastError());
-            HPT_DISPATCH_SCENE(S.variant, {
-                hipLaunchKernelGGL((k_wf_bounces<kS>), dim3(segments), dim3(wblock), lds_bytes(S, wblock), stream, S, max_depth, seg, q[0], q[1], ctx->d_live, accum, ctx->d_stats);
+            HPT_DISPATCH_RENDER(S.variant, ctx->has_glass, {
+                hipLaunchKernelGGL((k_wf_bounces<kS, kG>), dim3(segments), dim3(wblock), lds_bytes(S, wblock), stream, S, max_depth, seg, q[0], q[1], ctx->d_live, accum, ctx->d_stats);
             })
             HIP_TRY(hipGetLastError());
             launches += 2;

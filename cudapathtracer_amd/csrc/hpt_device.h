@@ -70,6 +70,7 @@ HD f3 cross(f3 x, f3 y) { return mk(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x
 HD float length(f3 v) { return sqrtf(dot(v, v)); }
 HD f3 normalize(f3 v) { return v * (1.0f / sqrtf(dot(v, v))); }
 HD float gmax(float x, float y) { return x > y ? x : y; }  // glm::max (external/glm/detail/func_common.inl:23-28): NaN -> y
+HD float gmin(float x, float y) { return x < y ? x : y; }  // glm::min (external/glm/detail/func_common.inl:15-19)
 HD f3 xyz(float4 v) { return mk(v.x, v.y, v.z); }
 
 // common/MathUtils.hpp:64-74
@@ -189,7 +190,7 @@ struct DevMaterial {
     float albedo_over_pi[3];   // albedo * 1.f / Pi            (Material.hpp:318)
     float f0[3];               // lerp(0.04, albedo, metallic)  (Material.hpp:335-336)
     float metallic, one_minus_metallic, roughness, rsq, rsq_minus_1;
-    float _pad;
+    float ior;                 // Glass only
 };  // 80 bytes
 enum : uint32_t { kMatEmitting = 1u, kMatSpecular = 2u };
 struct DevLight {
@@ -640,14 +641,99 @@ HD float luminance(f3 c) { return dot(c, mk(.2126f, .7152f, .0722f)); }
 
 HD f3 reflect(f3 ray_in_dir, f3 normal) { return ray_in_dir - dot(ray_in_dir, normal) * normal * 2.f; }  // :6-8
 
-// Material::pdf and Material::bsdf (Material.hpp:257-276, :315-347), Lambertian and
-// MetallicWorkflow, evaluated together because the integrator always needs both.
+// Dielectric helpers of Material::Type::Glass (Material.hpp:11-46).
+HD float clampf(float lo, float hi, float v) { return gmax(lo, gmin(hi, v)); }  // MathUtils.hpp:82-84
+HD f3 refract(f3 ray_in_dir, f3 normal, float ior) {
+    float cos_i = clampf(-1.0f, 1.0f, dot(ray_in_dir, normal));
+    float eta_i = 1.0f, eta_t = ior;
+    f3 correct_normal = normal;
+    if (cos_i < 0.0f) {
+        cos_i = -cos_i;
+    } else {
+        eta_i = ior;
+        eta_t = 1.0f;
+        correct_normal = -normal;
+    }
+    const float eta = eta_i / eta_t;
+    const float k = 1.0f - eta * eta * (1.0f - cos_i * cos_i);
+    if (k < 0.0f) return mk(0.0f);
+    return normalize(eta * ray_in_dir + (eta * cos_i - sqrtf(k)) * correct_normal);
+}
+HD float fresnel(f3 observation_dir, f3 normal, float ior) {
+    float cos_i = clampf(-1.0f, 1.0f, dot(observation_dir, normal));
+    float eta_i = 1.0f, eta_t = ior;
+    if (cos_i > 0.0f) {
+        eta_i = ior;
+        eta_t = 1.0f;
+    }
+    const float sin_t = eta_i / eta_t * sqrtf(gmax(0.0f, 1.0f - cos_i * cos_i));
+    if (sin_t >= 1.0f) return 1.0f;  // total internal reflection
+    const float cos_t = sqrtf(gmax(0.0f, 1.0f - sin_t * sin_t));
+    cos_i = fabsf(cos_i);
+    const float rs = ((eta_t * cos_i) - (eta_i * cos_t)) / ((eta_t * cos_i) + (eta_i * cos_t));
+    const float rp = ((eta_i * cos_i) - (eta_t * cos_t)) / ((eta_i * cos_i) + (eta_t * cos_t));
+    return (rs * rs + rp * rp) / 2;
+}
+
+// Material::pdf and Material::bsdf of Glass (Material.hpp:277-309, :348-381) with
+// Microfacet::outward_micro_surface_normal (:82-98) and refract_jacobian (:104-108).
+HD void glass_eval(float rsq, float rsq_minus_1, float roughness, float ior, f3 src, f3 out, f3 normal,
+                                        f3& bsdf, float& pdf) {
+    const float nds = dot(normal, src), ndo = dot(normal, out);
+    const float check = nds * ndo;
+    if (check == 0.0f) {
+        pdf = 0.0f;
+        bsdf = mk(0.0f);
+        return;
+    }
+    const bool same_side = check > 0.0f, outward = ndo > 0.0f;
+    f3 mm;
+    if (same_side) {
+        mm = normalize(src + out);
+        if (!outward) mm = -mm;
+    } else {
+        mm = outward ? -normalize(out + src * ior) : -normalize(ior * out + src);
+    }
+    const float F = fresnel(-out, mm, ior);
+    const float ndm = dot(normal, mm);
+    const float mds = dot(mm, src), mdo = dot(mm, out);
+    const float andm = fabsf(ndm);
+    // Microfacet::distribution (:48-53); |ndm|^2 == ndm^2, so D of pdf and bsdf are one value
+    float denominator = (ndm * ndm) * rsq_minus_1 + 1.0f;
+    denominator = kPi * denominator * denominator;
+    const float D = rsq / denominator;
+    const float pm = D * andm;                                                      // pdf_micro_surface (:76-80)
+    const float G = 2.0f / lerp(fabsf(2 * mds * mdo), fabsf(mds + mdo), roughness);  // geometry (:59-61)
+    if (same_side) {
+        const float jac = mdo == 0.0f ? 0.0f : 1.0f / (4 * fabsf(mdo));  // reflect_jacobian (:100-102)
+        pdf = pm * F * jac;
+        bsdf = mk(D * F * G / 4.0f);
+        return;
+    }
+    const float ior_in = nds < 0.0f ? ior : 1.0f, ior_out = ndo < 0.0f ? ior : 1.0f;
+    float den = ior_in * mds + ior_out * mdo;
+    den *= den;
+    const float jac = den == 0.0f ? 0.0f : (ior_out * ior_out * fabsf(mdo)) / den;
+    pdf = pm * (1.0f - F) * jac;
+    bsdf = mk(jac * fabsf(mds) * D * (1.0f - F) * G);
+}
+
+// Material::pdf and Material::bsdf (Material.hpp:257-312, :315-384), evaluated together
+// because the integrator always needs both.  kGlass = false compiles the Glass branch out:
+// kernels for scenes without a glass material pay nothing for it in registers.
+template <bool kGlass>
 HD void mat_eval(const DevMaterial& m, f3 src, f3 out, f3 normal, f3& bsdf, float& pdf) {
     if (m.type == 0) {
         const bool front = dot(out, normal) > 0.0f;
         pdf = front ? 0.5f * 1.f / kPi : 0.0f;
         bsdf = front ? mk(m.albedo_over_pi[0], m.albedo_over_pi[1], m.albedo_over_pi[2]) : mk(0.0f);
         return;
+    }
+    if constexpr (kGlass) {
+        if (m.type == 2) {
+            glass_eval(m.rsq, m.rsq_minus_1, m.roughness, m.ior, src, out, normal, bsdf, pdf);
+            return;
+        }
     }
     const float nds = dot(normal, src), ndo = dot(normal, out);
     const float check = nds * ndo;
@@ -674,8 +760,15 @@ HD void mat_eval(const DevMaterial& m, f3 src, f3 out, f3 normal, f3& bsdf, floa
     const f3 specular = D * F * G / 4.0f;
     bsdf = diffuse + specular;
 }
-// Material::sample (Material.hpp:186-199); r0/r1 are draws kSlotBsdf0/1
-HD f3 mat_sample(const DevMaterial& m, float r0, float r1, f3 ray_out_dir, f3 normal) {
+// The choice between reflection and transmission of Material::sample (Material.hpp:200-215)
+HD f3 glass_direction(f3 observation_dir, f3 micro, float ior, float r2) {
+    const float f = fresnel(observation_dir, micro, ior);
+    if (r2 < f) return reflect(observation_dir, micro);
+    return refract(observation_dir, micro, ior);
+}
+// Material::sample (Material.hpp:186-219); r0/r1/r2 are draws kSlotBsdf0/1/2
+template <bool kGlass>
+HD f3 mat_sample(const DevMaterial& m, float r0, float r1, float r2, f3 ray_out_dir, f3 normal) {
     if (m.type == 0) return sampleHemisphereCosine(normal, r0, r1);
     const float theta = portable_acos(sqrtf((1.0f - r0) / (m.rsq_minus_1 * r0 + 1.0f)));
     const float phi = 2 * kPi * r1;
@@ -683,6 +776,9 @@ HD f3 mat_sample(const DevMaterial& m, float r0, float r1, f3 ray_out_dir, f3 no
     portable_sincos(theta, st, ct);
     portable_sincos(phi, sp, cp);
     const f3 micro = local_to_world(mk(st * cp, st * sp, ct), normal);
+    if constexpr (kGlass) {
+        if (m.type == 2) return glass_direction(-ray_out_dir, micro, m.ior, r2);
+    }
     return reflect(-ray_out_dir, micro);
 }
 
@@ -720,7 +816,7 @@ HD void generate_camera_path(const DevScene& S, uint32_t pixel, uint32_t sample,
 // (hit_tri, hit_t); hit_tri < 0 = miss.  Returns false when the path ends on
 // this bounce for the reason "missed the scene" (remainingBounces = 0, :156-161);
 // the caller ends it after max_depth bounces otherwise.  Counts shadow queries.
-template <int kScene, uint32_t kShadowInc = 1u>
+template <int kScene, bool kGlass, uint32_t kShadowInc = 1u>
 HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, Path& p, int hit_tri, double hit_t,
                      uint32_t& shadow_queries PROF_ARG) {
     bool alive = true;
@@ -816,7 +912,7 @@ HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, TriQueue
                     const f3 wo = -p.d;
                     f3 bsdf;
                     float bsdfPdf;
-                    mat_eval(material, wi, wo, normal, bsdf, bsdfPdf);
+                    mat_eval<kGlass>(material, wi, wo, normal, bsdf, bsdfPdf);
                     const float cos_theta = satDot(normal, wi);
                     const float weight = powerHeuristic(lightPdf, bsdfPdf);
                     p.rad = p.rad + p.thr * lemit * bsdf * cos_theta * cos_theta_prime / r2 / lightSamplePdf * weight;
@@ -830,10 +926,10 @@ HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, TriQueue
         const DevMaterial& material = S.mats[__float_as_int(S.tris[4 * hit_tri + 1].w)];
         const u4 rb = philox4x32_10((uint32_t)p.depth, 1u, S.seed, 0u, p.pixel, p.sample);
         const f3 wo = -p.d;
-        const f3 wi = mat_sample(material, u01(rb.x), u01(rb.y), wo, normal);
+        const f3 wi = mat_sample<kGlass>(material, u01(rb.x), u01(rb.y), u01(rb.z), wo, normal);
         f3 bsdf;
         float pdf;
-        mat_eval(material, wi, wo, normal, bsdf, pdf);
+        mat_eval<kGlass>(material, wi, wo, normal, bsdf, pdf);
         p.pdf = pdf;
         if (pdf < kEpsilon5) break;  // the path keeps its ray and re-traces it (:238-240)
         p.specular = (material.flags & kMatSpecular) != 0;

@@ -181,9 +181,10 @@ hpt_scene_desc Scene::describe() const {
 // file names of common/Scene.cpp:25-73.
 Scene Scene::CreateBuiltinScene(Scene::BuiltinScene sceneId, int maxDepth) {
     if (sceneId == Scene::BuiltinScene::BunnyInCornell) return CreateBunnyScene(maxDepth);
-    if (sceneId != Scene::BuiltinScene::CornellBox) throw std::runtime_error("Unsupported sceneId");
+    if (sceneId != Scene::BuiltinScene::CornellBox && sceneId != Scene::BuiltinScene::GlassCornell)
+        throw std::runtime_error("Unsupported sceneId");
     Scene scene(512, 512);
-    scene.name = "Cornell Box";
+    scene.name = sceneId == Scene::BuiltinScene::GlassCornell ? "Glass Cornell" : "Cornell Box";
     scene.maxDepth = maxDepth;
     scene.camPos = Vec3(278, 273, -800);
 
@@ -197,7 +198,8 @@ Scene Scene::CreateBuiltinScene(Scene::BuiltinScene sceneId, int maxDepth) {
     metal._albedo = Vec3((float)0.7, (float)0.5, (float)0.2);
     metal._metallic = 1.f;
     metal._roughness = 0.005f;
-    glass.type = Material::Type::Lambertian;  // the "glass" short box is Lambertian in the reference too
+    // the "glass" short box is Lambertian in the reference's scene (common/Scene.cpp:45)
+    glass.type = sceneId == Scene::BuiltinScene::GlassCornell ? Material::Type::Glass : Material::Type::Lambertian;
     glass._roughness = 0.2f;
     glass._ior = 1.5f;
 

@@ -65,6 +65,9 @@ public:
         // ships the mesh but no scene that uses it; the same scene is defined, vertex for
         // vertex, in cudapathtracer_amd/scenes.py (bunny_in_cornell).
         BunnyInCornell,
+        // The Cornell box with the short box made of the glass that common/Scene.cpp:45-47
+        // parametrises (roughness 0.2, ior 1.5) but leaves Lambertian: Material::Type::Glass.
+        GlassCornell,
     };
     // OBJ files are opened as "models/<dir>/<name>.obj" relative to the
     // current directory, or under $HPT_MODELS_DIR when that is set.

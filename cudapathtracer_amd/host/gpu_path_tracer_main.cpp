@@ -28,9 +28,10 @@ int main(int argc, char** argv) {
     if (argc > 4) mode = (HipRenderMode)atoi(argv[4]);
 
     try {
-        // HPT_SCENE=bunny renders the bunny scene instead of the reference's only scene
+        // HPT_SCENE=bunny / glass renders one of the other built-in scenes instead of the reference's only one
         const char* which = getenv("HPT_SCENE");
-        Scene scene = Scene::CreateBuiltinScene(which && std::string(which) == "bunny" ? Scene::BunnyInCornell : Scene::CornellBox, maxDepth);
+        const std::string name = which ? which : "";
+        Scene scene = Scene::CreateBuiltinScene(name == "bunny" ? Scene::BunnyInCornell : name == "glass" ? Scene::GlassCornell : Scene::CornellBox, maxDepth);
         if (const char* w = getenv("HPT_WIDTH")) scene.width = atoi(w);
         if (const char* h = getenv("HPT_HEIGHT")) scene.height = atoi(h);
 

@@ -65,7 +65,7 @@ int hpt_host_scene_cornell(const char* models_dir, int width, int height, int ma
 int hpt_host_scene_builtin(int scene_id, const char* models_dir, int width, int height, int max_depth, hpt_host_scene** out) {
     if (!out) return fail("out is null");
     *out = nullptr;
-    if (scene_id != (int)Scene::CornellBox && scene_id != (int)Scene::BunnyInCornell) return fail("unknown built-in scene");
+    if (scene_id < (int)Scene::CornellBox || scene_id > (int)Scene::GlassCornell) return fail("unknown built-in scene");
     GUARD({
         if (models_dir) setenv("HPT_MODELS_DIR", models_dir, 1);
         Scene sc = Scene::CreateBuiltinScene((Scene::BuiltinScene)scene_id, max_depth);

@@ -9,6 +9,9 @@ arrays can be given to any other implementation of the reference's
 
 * ``bunny_in_cornell``  Cornell walls + light, the two boxes replaced by the
   Stanford bunny (4968 triangles) standing on the floor.
+* ``glass_cornell``  the reference's Cornell box with the short box made of the
+  glass the reference defines for it but never switches on (common/Scene.cpp:45-47:
+  roughness 0.2, ior 1.5, type left Lambertian): exercises ``Material::Type::Glass``.
 * ``heightfield_in_cornell(n)``  Cornell walls + light over an n x n displaced
   height field (2 n^2 triangles; n = 708 gives ~1.0 M): a BVH-fetch stress scene.
 
@@ -28,6 +31,7 @@ RED = dict(type=0, albedo=(0.63, 0.065, 0.05))
 GREEN = dict(type=0, albedo=(0.14, 0.45, 0.091))
 WHITE = dict(type=0, albedo=(0.725, 0.71, 0.68))
 METAL = dict(type=1, albedo=(0.7, 0.5, 0.2), metallic=1.0, roughness=0.005)
+GLASS = dict(type=2, roughness=0.2, ior=1.5)
 
 
 def light_emission():
@@ -108,12 +112,27 @@ def _assemble(parts, width, height, max_depth):
     return sc.buildBVH()
 
 
+def glass_cornell_parts(models_dir=DEFAULT_MODELS_DIR, glass=None):
+    """The six meshes of the reference's Cornell box in Scene::Add order (common/Scene.cpp:63-68)."""
+    d = os.path.join(models_dir, "cornellbox")
+    shell = {name: (tris, mat) for name, tris, mat in cornell_shell_triangles(models_dir)}
+    box = {n: read_obj_triangles(os.path.join(d, n + ".obj")) for n in ("shortbox", "tallbox")}
+    return [("floor",) + shell["floor"], ("shortbox", box["shortbox"], dict(glass or GLASS)), ("tallbox", box["tallbox"], METAL),
+            ("left",) + shell["left"], ("right",) + shell["right"], ("light",) + shell["light"]]
+
+
 def bunny_in_cornell_parts(models_dir=DEFAULT_MODELS_DIR):
     return cornell_shell_triangles(models_dir) + [("bunny", bunny_triangles(models_dir), WHITE)]
 
 
 def heightfield_in_cornell_parts(n, models_dir=DEFAULT_MODELS_DIR):
     return cornell_shell_triangles(models_dir) + [("heightfield", heightfield_triangles(n), WHITE)]
+
+
+def glass_cornell(width=1024, height=1024, max_depth=20, models_dir=DEFAULT_MODELS_DIR):
+    sc = _assemble(glass_cornell_parts(models_dir), width, height, max_depth)
+    sc.name = "Glass Cornell"
+    return sc
 
 
 def bunny_in_cornell(width=1024, height=1024, max_depth=20, models_dir=DEFAULT_MODELS_DIR):

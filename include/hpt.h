@@ -45,7 +45,7 @@ enum { HPT_MODE_SINGLE_KERNEL = 1, HPT_MODE_STREAMED = 2 };
 
 /* Material table entry; the fields of the reference's Material
  * (common/Material.hpp:130-142).  type: 0 Lambertian, 1 MetallicWorkflow, 2 Glass
- * (Glass is not yet traced on the device: upload rejects it). */
+ * (rough dielectric, Material.hpp:200-215, :277-309, :348-381; ior must be set). */
 typedef struct {
     int32_t type;
     float emission[3];

@@ -24,7 +24,9 @@ const char* hpt_host_last_error(void);
  * $HPT_MODELS_DIR); width/height <= 0 keep the built-in 512x512. */
 int hpt_host_scene_cornell(const char* models_dir, int width, int height, int max_depth, hpt_host_scene** out);
 /* Scene::CreateBuiltinScene(scene_id, max_depth): 0 = CornellBox as above, 1 = BunnyInCornell
- * (no counterpart in the reference, which ships models/bunny but no scene that uses it). */
+ * (no counterpart in the reference, which ships models/bunny but no scene that uses it),
+ * 2 = GlassCornell (CornellBox with the short box's material type switched to Glass; the
+ * reference sets that material's glass parameters, common/Scene.cpp:45-47, but not its type). */
 int hpt_host_scene_builtin(int scene_id, const char* models_dir, int width, int height, int max_depth, hpt_host_scene** out);
 /* empty scene: Scene(w, h) + camera (common/Scene.hpp:23-45) */
 int hpt_host_scene_create(int width, int height, const float cam_pos[3], double fov_deg, int max_depth,

@@ -14,13 +14,72 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
-from orclib import Material, Ref, fnv1a64, primary_rays, random_rays, shadow_rays  # noqa: E402
+from orclib import MODELS, Material, Ref, fnv1a64, primary_rays, random_rays, shadow_rays  # noqa: E402
 
 CAM = (278, 273, -800)
+
+# Material::Type::Glass (common/Material.hpp:200-215, :277-309, :348-381).  The reference's
+# built-in scene never selects it (common/Scene.cpp:45 sets the "glass" material to
+# Lambertian), so its vectors come from the reference's Material methods called directly and
+# from a Cornell box whose short box is given the reference's own glass parameters.
+GLASS_MATS = {
+    "glass": dict(type=2, roughness=0.2, ior=1.5),
+    "glass_water": dict(type=2, roughness=0.05, ior=1.33),
+    "glass_rough": dict(type=2, roughness=0.7, ior=2.4),
+}
+
+
+def glass_cornell_materials():
+    f = np.float32
+    e = (f(8.0) * np.array([f(0.747) + f(0.058), f(0.747) + f(0.258), f(0.747)], np.float32)
+         + f(15.6) * np.array([f(0.740) + f(0.287), f(0.740) + f(0.160), f(0.740)], np.float32)
+         + f(18.4) * np.array([f(0.737) + f(0.642), f(0.737) + f(0.159), f(0.737)], np.float32))
+    return [
+        ("floor", dict(type=0, albedo=(0.725, 0.71, 0.68))),
+        ("shortbox", GLASS_MATS["glass"]),
+        ("tallbox", dict(type=1, albedo=(0.7, 0.5, 0.2), metallic=1.0, roughness=0.005)),
+        ("left", dict(type=0, albedo=(0.63, 0.065, 0.05))),
+        ("right", dict(type=0, albedo=(0.14, 0.45, 0.091))),
+        ("light", dict(type=0, emission=tuple(float(v) for v in e))),
+    ]
+
+
+def glass(R):
+    g = {}
+    rs = np.random.RandomState(11)
+    n = 2048
+
+    def unit(v):
+        return (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+
+    # observer and light on either side of the surface: reflection and transmission,
+    # entering and leaving the medium
+    nrm, wo, wi = unit(rs.randn(n, 3)), unit(rs.randn(n, 3)), unit(rs.randn(n, 3))
+    nrm[:6] = np.array([[0, 1, 0], [0, -1, 0], [1, 0, 0], [-1, 0, 0], [0, 0, 1], [0, 0, -1]], np.float32)
+    wo[6:12] = unit(nrm[6:12] * 0.02 + unit(np.cross(nrm[6:12], wo[6:12])))  # grazing: total internal reflection
+    wo[12:18] = -wo[6:12]
+    g["nrm"], g["wo"], g["wi"] = nrm, wo, wi
+    for name, kw in GLASS_MATS.items():
+        m = Material.make(**kw)
+        g[name + "_bsdf"], g[name + "_pdf"] = R.material_eval(m, wi, wo, nrm)
+        w, u = R.material_sample(m, 300, 5, wo, nrm)
+        g[name + "_sample_wi"], g[name + "_sample_u"] = w, u
+        g[name + "_bsdf_at_sample"], g[name + "_pdf_at_sample"] = R.material_eval(m, w, wo, nrm)
+    # the glass Cornell box through the reference's own Scene::Add / Renderer::Render
+    for tag, w, h, depth, spp in (("r64_d8_spp4", 64, 64, 8, 4), ("r40x48_d20_spp2", 40, 48, 20, 2)):
+        R.begin(w, h, depth, CAM, 40.0)
+        for name, kw in glass_cornell_materials():
+            R.add_obj(os.path.join(MODELS, "cornellbox", name + ".obj"), Material.make(**kw))
+        R.build()
+        g["img_" + tag] = R.render(spp)
+    np.savez_compressed(os.path.join(HERE, "glass.npz"), **g)
+    R.cornell(5)
 
 
 def main():
     R = Ref().cornell(5)
+    if sys.argv[1:] == ["glass"]:
+        return glass(R)
     info = R.info()
     assert info["num_tris"] == 32 and info["node_counter"] == 69
 
@@ -143,6 +202,7 @@ def main():
     sh["tone_in"] = tv
     sh["tone_out"] = np.array([R.lib.ref_tonemap(float(v)) for v in tv], np.int32)
     np.savez_compressed(os.path.join(HERE, "cornell_shading.npz"), **sh)
+    glass(R)
     for f in sorted(os.listdir(HERE)):
         print("%8d  %s" % (os.path.getsize(os.path.join(HERE, f)), f))
 

@@ -74,6 +74,39 @@ def test_scene_hits_and_images(hp, oracle, gpu_ctx, name):
         assert np.array_equal(got.view(np.int32), oracle.resolve(want_acc, spp).view(np.int32)), "mode %d" % mode
 
 
+@pytest.mark.parametrize("name", ["cornell", "cornell_water", "bunny"])
+def test_glass_scenes(hp, oracle, gpu_ctx, name):
+    """Material::Type::Glass: the Cornell box with a glass short box (LDS marking variant) and a
+    glass bunny (two-child records): images and ray counters bit-exact against the oracle, whose
+    glass is pinned to the compiled reference by tests/golden/glass.npz."""
+    from cudapathtracer_amd import scenes
+    if name == "bunny":
+        parts = scenes.cornell_shell_triangles() + [("bunny", scenes.bunny_triangles(), dict(type=2, roughness=0.3, ior=1.45))]
+        w, h, depth, spp = 48, 40, 10, 2
+    else:
+        parts = scenes.glass_cornell_parts(glass=dict(type=2, roughness=0.05, ior=1.33) if name == "cornell_water" else None)
+        w, h, depth, spp = 64, 48, 12, 4
+    sc = scenes._assemble(parts, w, h, depth)
+    osc = _oracle_scene(oracle, parts, w, h)
+    gpu_ctx.upload(sc)
+    assert gpu_ctx.stats()["variant"] == (5 if name == "bunny" else 2)
+    want_acc, ost = osc.render(RNG_PHILOX, TRIG_PORTABLE, depth, spp, fixed=True)
+    # glass bounces are specular: the bounce after one sends no shadow ray
+    assert ost["shadow_queries"] < ost["closest_queries"]
+    for mode in (1, 2):
+        gpu_ctx.stats_reset()
+        gpu_ctx.accum_clear()
+        gpu_ctx.render(mode, 256, depth, 0, spp)
+        got = gpu_ctx.resolve(spp)
+        st = gpu_ctx.stats()
+        assert (st["closest_queries"], st["shadow_queries"]) == (ost["closest_queries"], ost["shadow_queries"])
+        assert np.array_equal(got.view(np.int32), oracle.resolve(want_acc, spp).view(np.int32)), "mode %d" % mode
+    if name == "cornell":
+        plain = _oracle_scene(oracle, scenes.glass_cornell_parts(glass=scenes.WHITE), w, h)
+        other, _ = plain.render(RNG_PHILOX, TRIG_PORTABLE, depth, spp, fixed=True)
+        assert not np.array_equal(other, want_acc)
+
+
 @pytest.mark.parametrize("variant", [0, 1])
 def test_forced_variants(hp, oracle, gpu_ctx, monkeypatch, variant):
     """the variants that are no scene's default: the threaded walk through L1/L2 (0) and from

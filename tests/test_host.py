@@ -212,6 +212,20 @@ def test_builtin_bunny_scene_equals_the_python_definition(hp):
     assert a["cam_scale"] == b["cam_scale"]
 
 
+def test_builtin_glass_cornell_equals_the_python_definition(hp):
+    """Scene::CreateBuiltinScene(GlassCornell) == scenes.glass_cornell: same flattened arrays, and
+    the only difference from CornellBox is the short box's material type."""
+    from cudapathtracer_amd import scenes
+    a = hp.Scene.CreateBuiltinScene(hp.Scene.GlassCornell, 7, 64, 48).flat_arrays()
+    b = scenes.glass_cornell(64, 48, 7).flat_arrays()
+    c = hp.Scene.CreateBuiltinScene(hp.Scene.CornellBox, 7, 64, 48).flat_arrays()
+    raw = lambda v: np.atleast_1d(np.asarray(v)).tobytes()
+    for k in a:
+        assert raw(a[k]) == raw(b[k]), k
+    diff = [k for k in a if raw(a[k]) != raw(c[k])]
+    assert diff == ["materials"], diff
+
+
 def test_scene_errors(hp, tmp_path):
     with pytest.raises(hp.HptError):
         hp.Scene.CreateBuiltinScene(hp.Scene.CornellBox, 5, models_dir=str(tmp_path))
@@ -227,7 +241,7 @@ def test_scene_errors(hp, tmp_path):
     with pytest.raises(hp.HptError):
         sc.describe()          # not built
     with pytest.raises(hp.HptError):
-        hp.Scene.CreateBuiltinScene(2, 5)   # 0 Cornell box, 1 bunny; nothing else
+        hp.Scene.CreateBuiltinScene(3, 5)   # 0 Cornell box, 1 bunny, 2 glass Cornell box; nothing else
 
 
 def test_save_ppm_tone_curve(hp, tmp_path):
