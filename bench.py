@@ -68,6 +68,9 @@ def main():
                     "workgroup schedules best (12.1 vs 11.0 Grays/s at 256)")
     ap.add_argument("--cpu-spp", type=int, default=8, help="samples of the CPU baseline leg (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traversal", default="reference", choices=["reference", "culled"],
+                    help="reference = the reference's box/triangle tests exactly (the parity path); culled = near-first "
+                         "order with distance culling for scenes of more than 64 triangles (opt-in, not bit-guaranteed)")
     ap.add_argument("--scene", default="cornell", help="cornell (the headline workload) | bunny | heightfield:<n> "
                     "(side measurements of the other configurations; they never change the default line)")
     args = ap.parse_args()
@@ -126,7 +129,10 @@ def main():
             scene = scenes.heightfield_in_cornell(int(args.scene.split(":")[1]), W, H, depth)
         else:
             sys.exit("unknown --scene " + args.scene)
-    ctx = hp.Context(dev_index).upload(scene)
+    ctx = hp.Context(dev_index)
+    if args.traversal == "culled":
+        ctx.set_traversal(1)
+    ctx.upload(scene)
     accum = torch.zeros(3 * W * H, dtype=torch.int64, device=dev)
     rgb = torch.zeros(3 * W * H, dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream()

@@ -1,5 +1,6 @@
 """MI355X-native path-tracing core behind the host interface of
 kevinsadi/CudaPathTracer (Scene / HipRenderer), see api.py."""
 from .api import (Context, HipRenderer, HptError, Material, SavePPM, SavePFM, Scene, SingleKernel, Streamed,  # noqa: F401
+                  TRAVERSAL_CULLED, TRAVERSAL_REFERENCE,
                   device_count, load_libraries)
 from .sharding import render_sharded, sample_range  # noqa: F401

@@ -104,6 +104,7 @@ def _declare(L, H):
     L.hpt_scene_upload.argtypes = [vp, C.POINTER(hpt_scene_desc)]
     L.hpt_set_seed.argtypes = [vp, u32]
     L.hpt_set_wavefront_capacity.argtypes = [vp, u64]
+    L.hpt_set_traversal.argtypes = [vp, C.c_int]
     L.hpt_accum_clear.argtypes = [vp, vp, vp]
     L.hpt_render.argtypes = [vp, i32, i32, i32, u32, u32, vp, vp]
     L.hpt_resolve.argtypes = [vp, vp, u32, vp, vp]
@@ -157,6 +158,9 @@ def _stream(stream):
     if stream is None:
         return None
     return getattr(stream, "cuda_stream", stream)
+
+
+TRAVERSAL_REFERENCE, TRAVERSAL_CULLED = 0, 1
 
 
 class Scene:
@@ -281,6 +285,11 @@ class Context:
 
     def set_seed(self, seed):
         _ck(self._L.hpt_set_seed(self._h, int(seed)))
+
+    def set_traversal(self, traversal):
+        """TRAVERSAL_REFERENCE (default, bit-exact) or TRAVERSAL_CULLED; applies to the next upload."""
+        _ck(self._L.hpt_set_traversal(self._h, int(traversal)))
+        return self
 
     def set_wavefront_capacity(self, paths):
         _ck(self._L.hpt_set_wavefront_capacity(self._h, int(paths)))

@@ -85,7 +85,7 @@ __global__ void k_intersect_batch(DevScene S, size_t n, const float* __restrict_
     extern __shared__ float4 lds[];
     stage_scene<kScene>(S, lds);
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    const TriQueue tq = make_tri_queue(reinterpret_cast<uint32_t*>(lds + S.lds_float4s));
+    const TriQueue tq = make_tri_queue<kScene>(reinterpret_cast<uint32_t*>(lds + S.lds_float4s));
 #ifdef HPT_PROFILE
     __shared__ unsigned long long prof_dummy[3 * kProfSections];
     ProfAcc prof;
@@ -143,7 +143,7 @@ k_render_mega(DevScene S, int max_depth, uint32_t s_begin_all, uint32_t s_count_
 #else
     const uint32_t prof_words = 0u;
 #endif
-    const TriQueue tq = make_tri_queue(reinterpret_cast<uint32_t*>(lds + S.lds_float4s) + waves_per_block * 768u + prof_words);
+    const TriQueue tq = make_tri_queue<kScene>(reinterpret_cast<uint32_t*>(lds + S.lds_float4s) + waves_per_block * 768u + prof_words);
     stage_scene<kScene>(S, lds);
 
     const uint32_t W = (uint32_t)S.width, H = (uint32_t)S.height;
@@ -384,7 +384,7 @@ k_wf_bounces(DevScene S, int max_depth, uint32_t seg, WfQueue q0, WfQueue q1, co
     stage_scene<kScene>(S, lds);
     const uint32_t lane = threadIdx.x & 63u;
     const size_t seg_base = (size_t)blockIdx.x * seg;
-    const TriQueue tq = make_tri_queue(reinterpret_cast<uint32_t*>(lds + S.lds_float4s));
+    const TriQueue tq = make_tri_queue<kScene>(reinterpret_cast<uint32_t*>(lds + S.lds_float4s));
     uint32_t n_closest = 0, n_shadow = 0;
 #ifdef HPT_PROFILE
     __shared__ unsigned long long prof_dummy[3 * kProfSections];
@@ -454,6 +454,7 @@ __global__ void k_resolve(const int64_t* __restrict__ accum, size_t n, double de
     case kSceneTiny32: { constexpr int kS = kSceneTiny32; __VA_ARGS__; } break;          \
     case kSceneTiny64: { constexpr int kS = kSceneTiny64; __VA_ARGS__; } break;          \
     case kScenePair: { constexpr int kS = kScenePair; __VA_ARGS__; } break;              \
+    case kScenePairCull: { constexpr int kS = kScenePairCull; __VA_ARGS__; } break;      \
     default: { constexpr int kS = kScenePairLds; __VA_ARGS__; } break;                   \
     }
 // the same with kG = "the scene has a Glass material" for the kernels that shade
@@ -472,6 +473,7 @@ struct hpt_ctx {
     int device = 0;
     int num_cus = 256;
     bool has_scene = false;
+    int traversal = HPT_TRAVERSAL_REFERENCE;
     bool has_glass = false;  // some material is Material::Type::Glass: selects the kernels that carry its branch
     DevScene S{};
     // scene arrays (device)
@@ -764,9 +766,9 @@ int settle_events(hpt_ctx* ctx) {
 // dynamic LDS of the traversal kernels: the staged scene (if any) + the per-lane
 // triangle queues of the variants that use them
 uint32_t lds_bytes(const DevScene& S, int block) {
-    const bool pair = S.variant == kScenePair || S.variant == kScenePairLds;
+    const bool pair = S.variant == kScenePair || S.variant == kScenePairLds || S.variant == kScenePairCull;
     const bool queue = pair || S.variant == kSceneGlobal || S.variant == kSceneLds;
-    return S.lds_float4s * 16u + (queue ? (uint32_t)block * kTriQueue * 4u : 0u) + (pair ? (uint32_t)block * S.stack_depth * 4u : 0u);
+    return S.lds_float4s * 16u + (queue ? (uint32_t)block * tri_queue_entries(S.variant) * 4u : 0u) + (pair ? (uint32_t)block * S.stack_depth * 4u : 0u);
 }
 
 int grid_for(const hpt_ctx* ctx, uint64_t work, int block) {
@@ -916,7 +918,7 @@ int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* sc) {
     }
     // Two-child records of the same tree (see DevScene::pairs).  Interior node i has the children
     // i + 1 and miss(i + 1); records are numbered in pre-order of the interior nodes.
-    uint32_t num_pairs = 0, stack_depth = 1;
+    uint32_t num_pairs = 0, stack_depth = 1, stack_depth_any = 1;
     {
         auto node_int = [&](size_t i, int word) {
             int32_t v;
@@ -929,6 +931,7 @@ int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* sc) {
         if (num_pairs) {
             std::vector<float> rec((size_t)num_pairs * 16);
             std::vector<uint32_t> need(num_pairs, 0);  // stack entries a walk below this record can hold at once
+            std::vector<uint32_t> need_any(num_pairs, 0);  // the same when either child may be walked first
             for (size_t i = nn; i-- > 0;) {
                 if (pair_of[i] < 0) continue;
                 const size_t l = i + 1, r = (size_t)node_int(l, 3);
@@ -948,8 +951,11 @@ int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* sc) {
                 const uint32_t nl = ref_l >= 0 ? need[ref_l] + (ref_r >= 0 ? 1u : 0u) : 0u;
                 const uint32_t nr = ref_r >= 0 ? need[ref_r] : 0u;
                 need[pair_of[i]] = std::max(nl, nr);
+                const uint32_t both = (ref_l >= 0 && ref_r >= 0) ? 1u : 0u;
+                need_any[pair_of[i]] = std::max(ref_l >= 0 ? need_any[ref_l] : 0u, ref_r >= 0 ? need_any[ref_r] : 0u) + both;
             }
             stack_depth = std::max(1u, need[0]);
+            stack_depth_any = std::max(1u, need_any[0]);
             HIP_TRY(hipMalloc((void**)&ctx->d_pairs, rec.size() * 4));
             HIP_TRY(hipMemcpy(ctx->d_pairs, rec.data(), rec.size() * 4, hipMemcpyHostToDevice));
         }
@@ -1000,14 +1006,27 @@ int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* sc) {
     else if (fits_tiny && nt <= 64) S.variant = kSceneTiny64;
     else if (pair_ok) S.variant = fits_pair ? kScenePairLds : kScenePair;
     else S.variant = fits ? kSceneLds : kSceneGlobal;
+    // the culled walk packs a record index into 22 bits of a stack entry
+    const bool cull_ok = num_pairs > 0 && num_pairs < (1u << 22) && stack_depth_any <= kMaxStackDepth;
+    if (ctx->traversal == HPT_TRAVERSAL_CULLED && cull_ok && (S.variant == kScenePair || S.variant == kScenePairLds)) S.variant = kScenePairCull;
     if (const char* e = getenv("HPT_TRACE_VARIANT")) {  // experiments: force another variant
         const int v = atoi(e);
+        if (v == kScenePairCull && cull_ok) S.variant = kScenePairCull;
         if (v == kSceneGlobal) S.variant = kSceneGlobal;
         else if (v == kSceneLds && fits) S.variant = kSceneLds;
         else if (v == kSceneTiny64 && fits_tiny && nt <= 64) S.variant = kSceneTiny64;
         else if (v == kSceneTiny32 && fits_tiny && nt <= 32) S.variant = kSceneTiny32;
         else if (v == kScenePair && pair_ok) S.variant = kScenePair;
         else if (v == kScenePairLds && pair_ok && fits_pair) S.variant = kScenePairLds;
+    }
+    if (S.variant == kScenePairCull) {
+        S.stack_depth = stack_depth_any;
+        double diag2 = 0;
+        for (int c = 0; c < 3; ++c) diag2 += ((double)S.root_hi[c] - S.root_lo[c]) * ((double)S.root_hi[c] - S.root_lo[c]);
+        const double diag = std::sqrt(diag2) > 0 ? std::sqrt(diag2) : 1.0;
+        S.cull_slack = (float)(1e-4 * diag);
+        S.cull_qscale = (float)(1023.0 / diag);
+        S.cull_qinv = (float)(diag / 1023.0 * (1.0 - 1e-6));  // rounded down: the unpacked distance never exceeds the packed one
     }
     if (S.variant == kSceneTiny32 || S.variant == kSceneTiny64) {
         std::vector<float> oct_nodes;
@@ -1028,6 +1047,14 @@ int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* sc) {
     default: S.lds_float4s = 0u; break;
     }
     ctx->has_scene = true;
+    return HPT_OK;
+}
+
+int hpt_set_traversal(hpt_ctx* ctx, int traversal) {
+    if (!ctx) return fail(HPT_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (traversal != HPT_TRAVERSAL_REFERENCE && traversal != HPT_TRAVERSAL_CULLED)
+        return fail(HPT_ERR_INVALID_ARGUMENT, "traversal %d is neither HPT_TRAVERSAL_REFERENCE nor HPT_TRAVERSAL_CULLED", traversal);
+    ctx->traversal = traversal;
     return HPT_OK;
 }
 

@@ -231,6 +231,9 @@ struct DevScene {
     uint32_t num_pairs;
     uint32_t stack_depth;  // entries of the per-lane traversal stack that no ray can exceed
     float root_lo[3], root_hi[3];  // bounds of node 0
+    // kScenePairCull only: slack of the distance tests (scene units), and the scale that packs a
+    // box-entry distance into the 10 bits above a stack entry's record index (and its inverse)
+    float cull_slack, cull_qscale, cull_qinv;
     unsigned long long* prof;  // diagnostic builds only (3 x kProfSections totals), else null
 };
 
@@ -247,6 +250,12 @@ enum {
     kScenePairLds = 6, // with a per-lane stack in LDS; one dependent fetch per two box tests.
                        // Records read through L1/L2 (5) or staged in LDS (6).  Same box tests,
                        // same leaves reached as the threaded walk, in a different order.
+    kScenePairCull = 7, // opt-in, NOT the reference's leaf-visit set: the records of (5), nearer child
+                       // first, boxes behind the origin or beyond the closest hit so far (shadow
+                       // rays: beyond the light) skipped.  The reference tests those boxes and
+                       // their triangles too and rejects the hits by t; results differ only where
+                       // float rounding lets a triangle's t fall outside its own box's range by
+                       // more than the slack.
 };
 
 // LDS byte address of a pointer into shared memory (the low half of its flat address), and a
@@ -263,7 +272,7 @@ HD float4 lds_read(uint32_t at) {
 // workgroup must call it; it ends with a workgroup barrier (also for the variants that stage nothing).
 template <int kScene>
 HD void stage_scene(const DevScene& S, float4* lds) {
-    if constexpr (kScene == kSceneGlobal || kScene == kScenePair) {
+    if constexpr (kScene == kSceneGlobal || kScene == kScenePair || kScene == kScenePairCull) {
         __syncthreads();
     } else if constexpr (kScene == kScenePairLds) {
         const uint32_t np = 4u * S.num_pairs, nt = 4u * S.num_tris;
@@ -321,6 +330,14 @@ HD bool box_hit(const float4 lo, const float4 hi, f3 o, f3 inv, bool nx, bool ny
 // finite: then no product can be NaN and near <= far holds per axis, so
 // near = min(a, b), far = max(a, b) equal the sign-selected values and the
 // reference's sequence of comparisons reduces to max(near) <= min(far).
+HD bool box_range_finite(const float4 lo, const float4 hi, f3 o, f3 inv, float& tnear, float& tfar) {
+    const float ax = (lo.x - o.x) * inv.x, bx = (hi.x - o.x) * inv.x;
+    const float ay = (lo.y - o.y) * inv.y, by = (hi.y - o.y) * inv.y;
+    const float az = (lo.z - o.z) * inv.z, bz = (hi.z - o.z) * inv.z;
+    tnear = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    tfar = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    return tnear <= tfar;
+}
 HD bool box_hit_finite(const float4 lo, const float4 hi, f3 o, f3 inv) {
     const float ax = (lo.x - o.x) * inv.x, bx = (hi.x - o.x) * inv.x;
     const float ay = (lo.y - o.y) * inv.y, by = (hi.y - o.y) * inv.y;
@@ -367,16 +384,24 @@ HD bool tri_hit(const float4* __restrict__ T, int tri, f3 o, f3 d, double& t_out
 // no result; an occluded shadow ray merely finishes its box walk first.
 
 // Per-lane queue of leaf triangles whose test is still to be run (all variants but the marking
-// ones): kTriQueue entries in LDS, entry k of a lane at q[k * stride].
+// ones): tri_queue_entries(variant) entries in LDS, entry k of a lane at q[k * stride].
 constexpr uint32_t kTriQueue = 8;
+// The depth-first variants run longer between two rounds of triangle tests (each round is as
+// long as the lane with the most candidates needs): 16 entries measured best for the reference
+// walk (+13 % on the bunny over 8, 24 is slower again: LDS per wave), 12 for the culled one,
+// which wants its hits early.
+__host__ __device__ constexpr uint32_t tri_queue_entries(int scene) {
+    return (scene == kScenePair || scene == kScenePairLds) ? 16u : scene == kScenePairCull ? 12u : kTriQueue;
+}
 struct TriQueue {
     uint32_t* q;
     uint32_t stride;
     uint32_t* stk;  // traversal stack of the pair variants: entry k of a lane at stk[k * stride]
 };
 // the per-lane LDS scratch of a workgroup starts at `base` (queues of all lanes, then stacks)
+template <int kScene>
 HD TriQueue make_tri_queue(uint32_t* base) {
-    return TriQueue{base + threadIdx.x, blockDim.x, base + kTriQueue * blockDim.x + threadIdx.x};
+    return TriQueue{base + threadIdx.x, blockDim.x, base + tri_queue_entries(kScene) * blockDim.x + threadIdx.x};
 }
 
 template <int kScene, bool kShadow>
@@ -386,7 +411,7 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
     if constexpr (kScene == kScenePairLds) {
         N = lds;  // pair records
         T = lds + 4u * S.num_pairs;
-    } else if constexpr (kScene == kScenePair) {
+    } else if constexpr (kScene == kScenePair || kScene == kScenePairCull) {
         N = S.pairs;
         T = S.tris;
     } else if constexpr (kScene == kSceneLds) {
@@ -484,24 +509,44 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
             }
         }
         PROF_T1(kShadow ? kProfTriS : kProfTriC);  // filter + tests (includes the box time, subtracted by the reader)
-    } else if constexpr (kScene == kScenePair || kScene == kScenePairLds) {
+    } else if constexpr (kScene == kScenePair || kScene == kScenePairLds || kScene == kScenePairCull) {
         // Depth-first over two-child records.  A record is visited iff its node's box was hit,
         // and both children's boxes are tested there: the same tests as the threaded walk makes
         // (it tests a node iff its parent was hit).  Leaves reached are queued and tested in a
         // loop of their own; the visit order differs from the reference's, so the closest-hit
         // update spells out its tie rule: among equal t the triangle visited first by the
         // reference (= lowest index, triangles are stored in its visit order) wins.
+        // kCull (see kScenePairCull): a child also has to lie in front of the origin and not
+        // beyond `cull_t`; of two interior children the nearer is walked first and the other
+        // waits on the stack with its entry distance (10 bits, rounded down), to be dropped
+        // when a closer hit has been found by then.
+        constexpr bool kCull = (kScene == kScenePairCull);
+        constexpr uint32_t kQueue = tri_queue_entries(kScene);
         const float kInf = __builtin_inff();
         const bool finite = fabsf(inv.x) < kInf && fabsf(inv.y) < kInf && fabsf(inv.z) < kInf;
+        const bool cull = kCull && finite;
+        const float behind = -S.cull_slack;
+        float cull_t = kShadow ? (float)limit * 1.000001f + S.cull_slack : kInf;
         const float4 rlo = make_float4(S.root_lo[0], S.root_lo[1], S.root_lo[2], 0.f);
         const float4 rhi = make_float4(S.root_hi[0], S.root_hi[1], S.root_hi[2], 0.f);
-        int cur = (finite ? box_hit_finite(rlo, rhi, o, inv) : box_hit(rlo, rhi, o, inv, nx, ny, nz)) ? 0 : -1;
+        int cur;
+        if (cull) {
+            float tn, tf;
+            cur = (box_range_finite(rlo, rhi, o, inv, tn, tf) && tf >= behind && tn <= cull_t) ? 0 : -1;
+        } else {
+            cur = (finite ? box_hit_finite(rlo, rhi, o, inv) : box_hit(rlo, rhi, o, inv, nx, ny, nz)) ? 0 : -1;
+        }
         uint32_t cnt = 0, sp = 0;
         for (;;) {
-            while (cur >= 0 && cnt + 2u <= kTriQueue) {
+            while (cur >= 0 && cnt + 2u <= kQueue) {
                 const float4 q0 = N[4 * cur], q1 = N[4 * cur + 1], q2 = N[4 * cur + 2], q3 = N[4 * cur + 3];
                 bool hl, hr;
-                if (finite) {
+                float tnl = 0.f, tnr = 0.f;
+                if (cull) {
+                    float tfl, tfr;
+                    hl = box_range_finite(q0, q1, o, inv, tnl, tfl) && tfl >= behind && tnl <= cull_t;
+                    hr = box_range_finite(q2, q3, o, inv, tnr, tfr) && tfr >= behind && tnr <= cull_t;
+                } else if (finite) {
                     hl = box_hit_finite(q0, q1, o, inv);
                     hr = box_hit_finite(q2, q3, o, inv);
                 } else {
@@ -518,19 +563,34 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
                     ++cnt;
                 }
                 const bool gl = hl && rl >= 0, gr = hr && rr >= 0;
-                if (gl) {
-                    if (gr) {
+                if (gl && gr) {
+                    if constexpr (kCull) {
+                        const bool right_first = tnr < tnl;
+                        const float tfar_child = right_first ? tnl : tnr;
+                        const uint32_t qd = (uint32_t)fminf(fmaxf(tfar_child, 0.f) * S.cull_qscale, 1023.f);
+                        tq.stk[sp * tq.stride] = (uint32_t)(right_first ? rl : rr) | (qd << 22);
+                        cur = right_first ? rr : rl;
+                    } else {
                         tq.stk[sp * tq.stride] = (uint32_t)rr;
-                        ++sp;
+                        cur = rl;
                     }
+                    ++sp;
+                } else if (gl) {
                     cur = rl;
                 } else if (gr) {
                     cur = rr;
-                } else if (sp) {
-                    --sp;
-                    cur = (int)tq.stk[sp * tq.stride];
                 } else {
                     cur = -1;
+                    while (sp) {
+                        --sp;
+                        uint32_t e = tq.stk[sp * tq.stride];
+                        if constexpr (kCull) {
+                            if ((float)(e >> 22) * S.cull_qinv > cull_t) continue;
+                            e &= 0x3FFFFFu;
+                        }
+                        cur = (int)e;
+                        break;
+                    }
                 }
             }
             if (cnt == 0) break;
@@ -549,6 +609,7 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
                         if (t < best_t || (t == best_t && tri < best)) {
                             best = tri;
                             best_t = t;
+                            if constexpr (kCull) cull_t = (float)t * 1.000001f + S.cull_slack;
                         }
                     }
                 }

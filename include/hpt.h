@@ -112,7 +112,8 @@ typedef struct {
     uint32_t launches;        /* kernel launches of hpt_render, summed since the last hpt_stats_reset        */
     uint32_t variant;         /* traversal variant chosen for the uploaded scene: 0 threaded walk through L1/L2,
                                  1 the same from LDS, 2/3 LDS with a 32-/64-bit leaf mask,
-                                 5 two-child records + stack through L1/L2, 6 the same from LDS */
+                                 5 two-child records + stack through L1/L2, 6 the same from LDS,
+                                 7 two-child records with distance culling (HPT_TRAVERSAL_CULLED)   */
 } hpt_stats;
 
 const char* hpt_last_error(void);
@@ -136,6 +137,18 @@ int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* scene);
  *   wavefront_capacity: paths in flight per streamed batch (default 1<<24: 2 GiB of path state)   */
 int hpt_set_seed(hpt_ctx* ctx, uint32_t seed);
 int hpt_set_wavefront_capacity(hpt_ctx* ctx, uint64_t paths);
+
+/* Traversal order for scenes of more than 64 triangles; takes effect at the next hpt_scene_upload.
+ *   HPT_TRAVERSAL_REFERENCE (default): exactly the boxes and triangles BVHAccel::getIntersection
+ *     (common/BVH.hpp:91-145) tests: no ordering, no distance culling; results bit-exact.
+ *   HPT_TRAVERSAL_CULLED: nearer child first, boxes behind the ray origin or beyond the closest
+ *     hit found so far (shadow rays: beyond shadowDistance) skipped -- the "near-first + t-culling"
+ *     the reference's README lists as future work.  Same hit except where float rounding puts a
+ *     triangle's t outside its own box's slab range by more than 1e-4 of the scene diagonal.
+ * No counterpart in the reference. */
+#define HPT_TRAVERSAL_REFERENCE 0
+#define HPT_TRAVERSAL_CULLED 1
+int hpt_set_traversal(hpt_ctx* ctx, int traversal);
 
 /* thrust::fill(framebuffer, 0) of CudaRenderer::Render (gpu_path_tracer/CudaRenderer.cu:56).
  * accum_dev = NULL clears the context's own buffer. */
