@@ -25,6 +25,7 @@ void HipRenderer::PrepareRender(const Scene& scene) {
         ctx = nullptr;
     }
     check(hpt_context_create(device, &ctx), "hpt_context_create");
+    check(hpt_set_traversal(ctx, traversal), "hpt_set_traversal");
     const hpt_scene_desc desc = scene.describe();
     check(hpt_scene_upload(ctx, &desc), "hpt_scene_upload");
     framebuffer.assign(num_pixels, Vec3(0.f));

@@ -19,6 +19,9 @@ private:
 public:
     int num_threads = 256;
     int device = 0;  // the reference always renders on device 0
+    // HPT_TRAVERSAL_REFERENCE (0, bit-exact, default) or HPT_TRAVERSAL_CULLED (1, opt-in); no
+    // counterpart in the reference
+    int traversal = 0;
     ~HipRenderer() override;
     void SetMode(HipRenderMode mode);
     void PrepareRender(const Scene& scene);

@@ -46,6 +46,7 @@ int main(int argc, char** argv) {
         r.SetMode(mode);
         r.num_threads = num_threads;
         if (const char* d = getenv("HPT_DEVICE")) r.device = atoi(d);
+        if (const char* t = getenv("HPT_TRAVERSAL")) r.traversal = std::string(t) == "culled" ? HPT_TRAVERSAL_CULLED : HPT_TRAVERSAL_REFERENCE;
 
         r.PrepareRender(scene);
         r.Render(scene);
