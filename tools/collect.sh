@@ -15,6 +15,14 @@ timeout -k 10 300 python bench.py --no-cpu-baseline --mode 2 --steps 3 --warmup 
 timeout -k 10 300 python bench.py --no-cpu-baseline --scene bunny --steps 3 --warmup 1 --spp-per-step 16 > $OUT/bench_bunny.json 2>> $OUT/bench.err || exit 1
 timeout -k 10 300 python bench.py --no-cpu-baseline --scene bunny --mode 2 --steps 3 --warmup 1 --spp-per-step 16 > $OUT/bench_bunny_mode2.json 2>> $OUT/bench.err || exit 1
 timeout -k 10 300 python bench.py --no-cpu-baseline --scene heightfield:708 --steps 2 --warmup 1 --spp-per-step 4 > $OUT/bench_heightfield.json 2>> $OUT/bench.err || exit 1
+timeout -k 10 300 python bench.py --no-cpu-baseline --scene heightfield:708 --mode 2 --steps 2 --warmup 1 --spp-per-step 4 > $OUT/bench_heightfield_mode2.json 2>> $OUT/bench.err || exit 1
+for m in 1 2; do
+  timeout -k 10 300 python bench.py --no-cpu-baseline --traversal culled --scene bunny --mode $m --steps 3 --warmup 1 --spp-per-step 16 > $OUT/bench_bunny_culled_mode$m.json 2>> $OUT/bench.err || exit 1
+  timeout -k 10 300 python bench.py --no-cpu-baseline --traversal culled --scene heightfield:708 --mode $m --steps 2 --warmup 1 --spp-per-step 4 > $OUT/bench_heightfield_culled_mode$m.json 2>> $OUT/bench.err || exit 1
+done
+bash tools/pmc_mem.sh ${TAG}_bunny --scene bunny --spp-per-step 16 > /dev/null 2>&1 || exit 1
+bash tools/pmc_mem.sh ${TAG}_hf --scene heightfield:708 --spp-per-step 4 > /dev/null 2>&1 || exit 1
+timeout -k 10 100 python tools/cull_probe.py > $OUT/cull_probe.txt 2>&1 || exit 1
 timeout -k 10 100 python tools/trace_bench.py > $OUT/trace_bench.txt 2>&1 || exit 1
 if [ -f build/libhpt_prof.so ]; then
   HPT_LIBHPT=$PWD/build/libhpt_prof.so timeout -k 10 200 python bench.py --no-cpu-baseline --steps 1 --warmup 0 --spp-per-step 64 2>&1 | grep PROF > $OUT/section_profile.txt
