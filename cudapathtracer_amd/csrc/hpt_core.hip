@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <functional>
 #include <vector>
 
 #include "hpt_device.h"
@@ -634,6 +635,21 @@ int validate_scene(const hpt_scene_desc* sc) {
 // its other child when that child's box lies inside its own: then the child's slab test can
 // only succeed where the parent's would (float subtraction and multiplication are monotone),
 // so the set of triangles reached is unchanged.
+//
+// The same monotonicity goes further.  When every node's box lies inside its parent's (true of
+// any tree whose interior boxes are min/max unions, as BVHAccel::recursiveBuild makes them,
+// common/BVH.cpp:66-118), a ray with finite reciprocals that hits a leaf's box hits all of the
+// leaf's ancestors, so the triangles the reference tests are exactly those whose LEAF box is
+// hit -- the interior nodes decide nothing, they only save tests.  The octant copies are
+// therefore free to use a tree of their own over the octant's live leaves, as long as each of
+// its boxes is again the union of the leaf boxes below it.  `nested` scenes get one built for
+// few box tests: leaves are merged bottom-up, always the pair with the smallest union surface
+// area (the chance that a line crossing the scene crosses a box is proportional to its area),
+// and an interior node is then dropped again when testing it costs more than it saves: with q
+// = area / scene area, its test is made with probability q(parent) and spares its k children's
+// tests with probability q(parent) - q(node).  The Cornell box goes from 17.6 to 10.2 box tests
+// per ray.  Copy 8 (rays with a zero direction component, for which the argument does not
+// hold: 0 * inf = NaN) always keeps the reference's tree.
 void build_octant_copies(const hpt_scene_desc* sc, bool leaf_bits, std::vector<float>& out_nodes, std::vector<uint32_t>& out_table) {
     const uint32_t nn = sc->num_nodes, nt = sc->num_tris;
     out_nodes.assign((size_t)9 * nn * 8, 0.f);
@@ -648,6 +664,17 @@ void build_octant_copies(const hpt_scene_desc* sc, bool leaf_bits, std::vector<f
         uint32_t miss;  // index of the miss target inside the copy
         int32_t tri;
     };
+    // every node's box inside its parent's (NaN bounds compare false: not nested)
+    bool nested = true;
+    for (uint32_t i = 0; i < nn && nested; ++i) {
+        if (node_int(i, 7) >= 0) continue;
+        const uint32_t kids[2] = {i + 1, (uint32_t)node_int(i + 1, 3)};
+        for (uint32_t ch : kids)
+            for (int c = 0; c < 3; ++c)
+                if (!(sc->nodes[8 * (size_t)ch + c] >= sc->nodes[8 * (size_t)i + c] && sc->nodes[8 * (size_t)ch + 4 + c] <= sc->nodes[8 * (size_t)i + 4 + c]))
+                    nested = false;
+    }
+    if (const char* e = getenv("HPT_OCTANT_TREES")) nested = nested && atoi(e) != 0;  // 0: keep the reference's topology (A/B runs)
     for (uint32_t k = 0; k < 9; ++k) {
         const bool whole = k == 8;
         const float sgn[3] = {(k & 1u) ? -1.f : 1.f, (k & 2u) ? -1.f : 1.f, (k & 4u) ? -1.f : 1.f};
@@ -674,6 +701,97 @@ void build_octant_copies(const hpt_scene_desc* sc, bool leaf_bits, std::vector<f
             return true;
         };
         std::vector<Rec> recs;
+        if (!whole && nested) {
+            struct Box {
+                float lo[3], hi[3];
+                int32_t tri;
+                std::vector<int> kids;
+            };
+            std::vector<Box> pool;
+            std::vector<int> roots;
+            for (uint32_t i = 0; i < nn; ++i) {
+                const int32_t tri = node_int(i, 7);
+                if (tri < 0 || rejected[tri]) continue;
+                Box b;
+                for (int c = 0; c < 3; ++c) {
+                    b.lo[c] = sc->nodes[8 * (size_t)i + c];
+                    b.hi[c] = sc->nodes[8 * (size_t)i + 4 + c];
+                }
+                b.tri = tri;
+                roots.push_back((int)pool.size());
+                pool.push_back(b);
+            }
+            auto area = [](const float* lo, const float* hi) {
+                const double dx = std::max(0.0, (double)hi[0] - lo[0]), dy = std::max(0.0, (double)hi[1] - lo[1]), dz = std::max(0.0, (double)hi[2] - lo[2]);
+                return 2.0 * (dx * dy + dy * dz + dx * dz);
+            };
+            while (roots.size() > 1) {
+                size_t bx = 0, by = 1;
+                double best = -1.0;
+                for (size_t x = 0; x < roots.size(); ++x)
+                    for (size_t y = x + 1; y < roots.size(); ++y) {
+                        float lo[3], hi[3];
+                        for (int c = 0; c < 3; ++c) {
+                            lo[c] = std::min(pool[roots[x]].lo[c], pool[roots[y]].lo[c]);
+                            hi[c] = std::max(pool[roots[x]].hi[c], pool[roots[y]].hi[c]);
+                        }
+                        const double a = area(lo, hi);
+                        if (best < 0.0 || a < best) {
+                            best = a;
+                            bx = x;
+                            by = y;
+                        }
+                    }
+                Box u;
+                for (int c = 0; c < 3; ++c) {
+                    u.lo[c] = std::min(pool[roots[bx]].lo[c], pool[roots[by]].lo[c]);
+                    u.hi[c] = std::max(pool[roots[bx]].hi[c], pool[roots[by]].hi[c]);
+                }
+                u.tri = -1;
+                u.kids = {roots[bx], roots[by]};
+                roots.erase(roots.begin() + (long)by);
+                roots.erase(roots.begin() + (long)bx);
+                roots.push_back((int)pool.size());
+                pool.push_back(u);
+            }
+            const double scene_area = area(&sc->nodes[0], &sc->nodes[4]);
+            auto q_of = [&](int n) { return scene_area > 0.0 ? std::min(1.0, area(pool[n].lo, pool[n].hi) / scene_area) : 1.0; };
+            // children lists after dropping the interior nodes that do not pay
+            std::function<void(int, double, std::vector<int>&)> keep = [&](int n, double q_parent, std::vector<int>& out) {
+                if (pool[n].tri >= 0) {
+                    out.push_back(n);
+                    return;
+                }
+                const double q = q_of(n);
+                std::vector<int> kids;
+                for (int c : std::vector<int>(pool[n].kids)) keep(c, q, kids);
+                if (q > q_parent * (1.0 - 1.0 / (double)kids.size())) {
+                    out.insert(out.end(), kids.begin(), kids.end());
+                } else {
+                    pool[n].kids = kids;
+                    out.push_back(n);
+                }
+            };
+            std::vector<int> top;
+            if (!roots.empty()) keep(roots[0], 1.0, top);
+            std::function<void(int)> emit = [&](int n) {
+                Rec rc;
+                for (int c = 0; c < 3; ++c) {
+                    rc.lo[c] = pool[n].lo[c];
+                    rc.hi[c] = pool[n].hi[c];
+                }
+                rc.tri = pool[n].tri;
+                rc.miss = 0;
+                const size_t at = recs.size();
+                recs.push_back(rc);
+                if (rc.tri < 0)
+                    for (int c : pool[n].kids) emit(c);
+                recs[at].miss = (uint32_t)recs.size();
+            };
+            for (int n : top) emit(n);
+        }
+        const bool rebuilt = !whole && nested && recs.size() <= nn;
+        if (!rebuilt) recs.clear();
         // explicit stack of (node, index of the record to patch when the subtree is complete | ~0u)
         struct Item {
             uint32_t node;
@@ -681,7 +799,7 @@ void build_octant_copies(const hpt_scene_desc* sc, bool leaf_bits, std::vector<f
             uint32_t rec;
         };
         std::vector<Item> stack;
-        stack.push_back({0u, false, 0u});
+        if (!rebuilt) stack.push_back({0u, false, 0u});
         while (!stack.empty()) {
             const Item it = stack.back();
             stack.pop_back();
