@@ -663,6 +663,7 @@ void build_octant_copies(const hpt_scene_desc* sc, bool leaf_bits, std::vector<f
         float lo[3], hi[3];
         uint32_t miss;  // index of the miss target inside the copy
         int32_t tri;
+        uint32_t bits;  // leaf_bits: the leaf's triangles in the pending mask
     };
     // every node's box inside its parent's (NaN bounds compare false: not nested)
     bool nested = true;
@@ -705,6 +706,7 @@ void build_octant_copies(const hpt_scene_desc* sc, bool leaf_bits, std::vector<f
             struct Box {
                 float lo[3], hi[3];
                 int32_t tri;
+                uint32_t bits;
                 std::vector<int> kids;
             };
             std::vector<Box> pool;
@@ -718,6 +720,18 @@ void build_octant_copies(const hpt_scene_desc* sc, bool leaf_bits, std::vector<f
                     b.hi[c] = sc->nodes[8 * (size_t)i + 4 + c];
                 }
                 b.tri = tri;
+                b.bits = leaf_bits ? 1u << tri : 0u;
+                // leaves with the same box pass or fail together: with a mask as the leaf word one
+                // record serves them all (the two triangles of a rectangle have the same bounds)
+                bool merged = false;
+                if (leaf_bits)
+                    for (int r : roots)
+                        if (std::memcmp(pool[r].lo, b.lo, sizeof b.lo) == 0 && std::memcmp(pool[r].hi, b.hi, sizeof b.hi) == 0) {
+                            pool[r].bits |= b.bits;
+                            merged = true;
+                            break;
+                        }
+                if (merged) continue;
                 roots.push_back((int)pool.size());
                 pool.push_back(b);
             }
@@ -748,6 +762,7 @@ void build_octant_copies(const hpt_scene_desc* sc, bool leaf_bits, std::vector<f
                     u.hi[c] = std::max(pool[roots[bx]].hi[c], pool[roots[by]].hi[c]);
                 }
                 u.tri = -1;
+                u.bits = 0u;
                 u.kids = {roots[bx], roots[by]};
                 roots.erase(roots.begin() + (long)by);
                 roots.erase(roots.begin() + (long)bx);
@@ -781,6 +796,7 @@ void build_octant_copies(const hpt_scene_desc* sc, bool leaf_bits, std::vector<f
                     rc.hi[c] = pool[n].hi[c];
                 }
                 rc.tri = pool[n].tri;
+                rc.bits = pool[n].bits;
                 rc.miss = 0;
                 const size_t at = recs.size();
                 recs.push_back(rc);
@@ -824,6 +840,7 @@ void build_octant_copies(const hpt_scene_desc* sc, bool leaf_bits, std::vector<f
                 rc.hi[c] = sc->nodes[8 * (size_t)i + 4 + c];
             }
             rc.tri = node_int(i, 7);
+            rc.bits = rc.tri >= 0 && rc.tri < 32 ? 1u << rc.tri : 0u;
             rc.miss = (uint32_t)recs.size() + 1u;  // leaf: the next record
             recs.push_back(rc);
             if (rc.tri < 0) {
@@ -844,7 +861,7 @@ void build_octant_copies(const hpt_scene_desc* sc, bool leaf_bits, std::vector<f
             const uint32_t link = (k * nn + recs[j].miss) * 32u;
             std::memcpy(&q[3], &link, 4);
             uint32_t leaf = (uint32_t)recs[j].tri;
-            if (leaf_bits) leaf = recs[j].tri >= 0 ? 1u << recs[j].tri : 0u;
+            if (leaf_bits) leaf = recs[j].bits;
             std::memcpy(&q[7], &leaf, 4);
         }
         if (!whole) {
