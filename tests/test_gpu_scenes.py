@@ -175,6 +175,36 @@ def test_forced_variants(hp, oracle, gpu_ctx, monkeypatch, variant):
         assert np.array_equal(gpu_ctx.resolve(spp).view(np.int32), oracle.resolve(want_acc, spp).view(np.int32))
 
 
+@pytest.mark.parametrize("name", ["cornell", "soup40"])
+def test_octant_copies_on_the_reference_topology(hp, oracle, gpu_ctx, monkeypatch, name):
+    """HPT_OCTANT_TREES=0: the marking variants walk the reference's own tree (pruned per octant)
+    instead of the trees they build for themselves -- the path taken by scenes whose boxes are not
+    nested.  Same hits, same image, and both equal the oracle."""
+    from cudapathtracer_amd import scenes
+    if name == "cornell":
+        parts = scenes.glass_cornell_parts(glass=scenes.WHITE)
+    else:
+        light = dict(type=0, emission=scenes.light_emission())
+        quad = np.array([[[100, 500, 100], [400, 500, 100], [400, 500, 400]],
+                         [[100, 500, 100], [400, 500, 400], [100, 500, 400]]], np.float32)[:, ::-1]
+        parts = [("light", quad, light), ("a", _soup(25, 14), scenes.WHITE), ("b", _soup(13, 15), scenes.METAL)]
+    w, h, depth, spp = 40, 32, 6, 3
+    sc = scenes._assemble(parts, w, h, depth)
+    osc = _oracle_scene(oracle, parts, w, h)
+    want_acc, _ = osc.render(RNG_PHILOX, TRIG_PORTABLE, depth, spp, fixed=True)
+    for own_trees in ("0", "1"):
+        monkeypatch.setenv("HPT_OCTANT_TREES", own_trees)
+        gpu_ctx.upload(sc)
+        monkeypatch.delenv("HPT_OCTANT_TREES")
+        assert gpu_ctx.stats()["variant"] == (2 if name == "cornell" else 3)
+        _same_hits(gpu_ctx, osc, *random_rays(1 << 15, 71))
+        _same_hits(gpu_ctx, osc, *_shadow_batch(1 << 14, 72))
+        for mode in (1, 2):
+            gpu_ctx.accum_clear()
+            gpu_ctx.render(mode, 128, depth, 0, spp)
+            assert np.array_equal(gpu_ctx.resolve(spp).view(np.int32), oracle.resolve(want_acc, spp).view(np.int32))
+
+
 def _soup(n, seed, size=200.0):
     """n random triangles around the centre of the Cornell volume"""
     rs = np.random.RandomState(seed)
