@@ -1236,6 +1236,15 @@ int hpt_render(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sample
     const uint64_t lanes = (uint64_t)tiles * 64ull;  // lanes per sample (edge tiles are partly idle)
     const uint32_t lds = lds_bytes(S, 0);  // scene only; queues are added per launch below
 
+    // A workgroup stages the scene in LDS for itself (variants 1, 2, 3, 6: 20 KiB for the Cornell
+    // box), so small workgroups leave most of a CU's wave slots empty (64 lanes: half the speed of
+    // 256).  No result depends on the workgroup size, so such scenes are run with at least 256
+    // lanes per workgroup; HPT_EXACT_BLOCK=1 keeps the size asked for.
+    if (S.lds_float4s > 0 && block < 256) {
+        const char* e = getenv("HPT_EXACT_BLOCK");
+        if (!(e && atoi(e) != 0)) block = 256;
+    }
+
     hipEvent_t ev0 = take_event(ctx), ev1 = take_event(ctx);
     HIP_TRY(hipEventRecord(ev0, stream));
     uint32_t launches = 0;

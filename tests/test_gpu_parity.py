@@ -137,7 +137,9 @@ def test_accumulators_bit_exact_and_split_invariant(hp, oracle, gpu_ctx):
 
 @pytest.mark.parametrize("block", [64, 100, 512, 1024])
 @pytest.mark.parametrize("mode", [1, 2])
-def test_block_sizes_give_identical_images(hp, oracle, gpu_ctx, block, mode):
+def test_block_sizes_give_identical_images(hp, oracle, gpu_ctx, monkeypatch, block, mode):
+    # workgroups of exactly `block` lanes (LDS-resident scenes would otherwise run with at least 256)
+    monkeypatch.setenv("HPT_EXACT_BLOCK", "1")
     w, h, depth, spp = 40, 24, 6, 2   # 40x24: partial 8x8 tiles on neither edge... 24 = 3 tiles, 40 = 5 tiles
     sc = hp.Scene.CreateBuiltinScene(hp.Scene.CornellBox, depth, w + 3, h + 5)  # ragged edges
     osc = oracle.cornell(w + 3, h + 5)
@@ -161,7 +163,7 @@ def test_sample_chunks_and_spare_waves(hp, oracle, gpu_ctx):
     osc = oracle.cornell(w, h)
     gpu_ctx.upload(sc)
     want_acc, ost = osc.render(RNG_PHILOX, TRIG_PORTABLE, depth, spp, fixed=True)
-    for block in (128, 1024):
+    for block in (128, 1024):    # 128 is run as 256: the scene is staged in LDS per workgroup
         gpu_ctx.accum_clear()
         gpu_ctx.stats_reset()
         gpu_ctx.render(1, block, depth, 0, spp)
@@ -172,10 +174,13 @@ def test_sample_chunks_and_spare_waves(hp, oracle, gpu_ctx):
         assert np.array_equal(got.view(np.int32), oracle.resolve(want_acc, spp).view(np.int32))
 
 
+@pytest.mark.parametrize("exact_block", ["1", "0"])
 @pytest.mark.parametrize("mode", [1, 2])
-def test_extreme_shapes(hp, oracle, gpu_ctx, mode):
+def test_extreme_shapes(hp, oracle, gpu_ctx, monkeypatch, mode, exact_block):
     """a one-pixel image with one lane per workgroup, a one-row image, depth 1, and a sample range
-    that ends at the top of the 32-bit sample index space."""
+    that ends at the top of the 32-bit sample index space; with the workgroup size as given and
+    widened to 256."""
+    monkeypatch.setenv("HPT_EXACT_BLOCK", exact_block)
     for (w, h, block, depth, s0, spp) in ((1, 1, 1, 3, 0, 5), (19, 1, 7, 1, 0, 3), (9, 10, 64, 4, 0xFFFFFFF0, 15)):
         sc = hp.Scene.CreateBuiltinScene(hp.Scene.CornellBox, depth, w, h)
         osc = oracle.cornell(w, h)
