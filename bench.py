@@ -27,9 +27,10 @@ sys.path.insert(0, ROOT)
 # dense FP32 vector peak of MI355X (157.3 TFLOP/s counts an FMA as 2 flops)
 PEAK_FP32_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0
-# algorithmic work per unit (see DESIGN.md "Measurement"): one box test = 24
-# flops / one 32-byte node record... priced at 64 B like a triangle record;
-# one triangle test = 70 flops / 64 B; one shaded bounce = 350 flops
+# algorithmic work per unit: one box test = 24 flops (6 sub, 6 mul, ~12 compare/select) and one
+# node record, priced at 64 B like a triangle record; one triangle test = 70 flops / 64 B; one
+# shaded bounce = 350 flops.  Tests are counted as the reference traversal defines them, by the
+# CPU restatement, not by what the GPU kernel happens to execute.
 FLOPS_BOX, FLOPS_TRI, FLOPS_BOUNCE = 24.0, 70.0, 350.0
 BYTES_BOX, BYTES_TRI = 64.0, 64.0
 
@@ -188,7 +189,7 @@ def main():
             cpu, per_ray = cpu_baseline(W, H, depth, args.cpu_spp, threads)
         if per_ray is None:
             # reference traversal cost of this workload measured once with the CPU
-            # restatement (Cornell 1024x1024, depth 20); see DESIGN.md
+            # restatement (Cornell 1024x1024, depth 20)
             per_ray = {"box_per_ray": 29.33, "tri_per_ray": 5.62, "rays_per_path": 11.64}
 
         launches = max(1, st["launches"])

@@ -1,5 +1,5 @@
 #!/bin/bash
-# One GPU call that gathers everything quoted in DESIGN.md for the current build:
+# One GPU call that gathers the benchmark, profile and counter files kept under profiles/ for the current build:
 #   tools/collect.sh <tag>     (run on the GPU box from the repo root; results under gpurun_out/<tag>/)
 set -u
 TAG=$1
