@@ -1046,6 +1046,20 @@ int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* sc) {
             // luminance(Le) * 2 * pi * triangleArea / sumLightPower (common/Scene.hpp:179, :215)
             tris[16 * t + 3] = lum(sc->materials[mat].emission) * 2.f * pi * area / sc->sum_light_power;
         }
+        // Word 15 of the device copy (the mesh index, which no kernel reads): for scenes of up to 32
+        // triangles the mask of the triangles that have this triangle's normal (a zero of either
+        // sign counts as the same value: it contributes +-0 to dot(d, n) either way).  The
+        // back-face filter of the 32-triangle marking variant settles a whole group with one test.
+        if (nt <= 32) {
+            auto same = [](float a, float b) { return (a == 0.f && b == 0.f) || std::memcmp(&a, &b, 4) == 0; };
+            for (size_t t = 0; t < nt; ++t) {
+                uint32_t group = 0;
+                for (size_t u = 0; u < nt; ++u)
+                    if (same(tris[16 * t + 12], tris[16 * u + 12]) && same(tris[16 * t + 13], tris[16 * u + 13]) && same(tris[16 * t + 14], tris[16 * u + 14]))
+                        group |= 1u << u;
+                std::memcpy(&tris[16 * t + 15], &group, 4);
+            }
+        }
         HIP_TRY(hipMemcpy(ctx->d_tris, tris.data(), nt * 64, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(ctx->d_mats, mats.data(), mats.size() * sizeof(DevMaterial), hipMemcpyHostToDevice));
         ctx->has_glass = glass;

@@ -482,11 +482,23 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
         PROF_T1(kShadow ? kProfBoxS : kProfBoxC);
         // cheap filter first: drop back-facing triangles, so that the expensive rounds below are
         // only as many as the busiest lane needs.  Most triangles are decided by the octant alone.
-        for (mask_t m = undecided; m;) {
-            const int tri = kMask32 ? __ffs((int)m) - 1 : __ffsll((long long)m) - 1;
-            const mask_t rest = m & (m - 1);
-            if (dot(d, xyz(T[4 * tri + 3])) > 0) pending ^= m ^ rest;  // m ^ rest = the bit just examined
-            m = rest;
+        if constexpr (kMask32) {
+            // word 3 of the normal's float4 = mask of the triangles with the same normal (set at
+            // upload): one test settles them all (the two triangles of a rectangle)
+            for (uint32_t m = undecided; m;) {
+                const int tri = __ffs((int)m) - 1;
+                const float4 nr = T[4 * tri + 3];
+                const uint32_t group = __float_as_uint(nr.w);
+                if (dot(d, xyz(nr)) > 0) pending &= ~group;
+                m &= ~group;
+            }
+        } else {
+            for (mask_t m = undecided; m;) {
+                const int tri = __ffsll((long long)m) - 1;
+                const mask_t rest = m & (m - 1);
+                if (dot(d, xyz(T[4 * tri + 3])) > 0) pending ^= m ^ rest;  // m ^ rest = the bit just examined
+                m = rest;
+            }
         }
         while (pending) {
             PROF_ITER(kShadow ? kProfTriS : kProfTriC);
