@@ -105,6 +105,7 @@ def _declare(L, H):
     L.hpt_set_seed.argtypes = [vp, u32]
     L.hpt_set_wavefront_capacity.argtypes = [vp, u64]
     L.hpt_set_traversal.argtypes = [vp, C.c_int]
+    L.hpt_octant_copies.argtypes = [C.POINTER(hpt_scene_desc), C.c_int, vp, vp]
     L.hpt_accum_clear.argtypes = [vp, vp, vp]
     L.hpt_render.argtypes = [vp, i32, i32, i32, u32, u32, vp, vp]
     L.hpt_resolve.argtypes = [vp, vp, u32, vp, vp]
@@ -237,6 +238,16 @@ class Scene:
             lights=[(L.area, L.root_area, L.root_node, L.material) for L in (d.lights[i] for i in range(d.num_lights))],
             sum_light_area=d.sum_light_area, sum_light_power=d.sum_light_power, cam_scale=d.cam_scale,
             cam_pos=tuple(d.cam_pos), width=d.width, height=d.height)
+
+    def octant_copies(self, leaf_bits=True):
+        """The per-octant node copies hpt_scene_upload derives for a scene of up to 32 (64) triangles:
+        (nodes float32[9, num_nodes, 8], table uint32[32]).  Host only."""
+        L = load_libraries()[0]
+        d = self.describe()
+        nodes = np.zeros((9, d.num_nodes, 8), np.float32)
+        table = np.zeros(32, np.uint32)
+        _ck(L.hpt_octant_copies(C.byref(d), 1 if leaf_bits else 0, nodes.ctypes.data, table.ctypes.data))
+        return nodes, table
 
     def bvh_dump(self, mesh):
         n = C.c_int()

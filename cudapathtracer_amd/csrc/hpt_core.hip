@@ -1227,6 +1227,18 @@ int hpt_accum_buffer(hpt_ctx* ctx, int64_t** accum_dev, size_t* num_elements) {
     return HPT_OK;
 }
 
+int hpt_octant_copies(const hpt_scene_desc* sc, int leaf_bits, float* nodes_out, uint32_t* table_out) {
+    if (!sc || !nodes_out || !table_out) return fail(HPT_ERR_INVALID_ARGUMENT, "null argument");
+    if (int rc = validate_scene(sc)) return rc;
+    if (sc->num_tris > (leaf_bits ? 32u : 64u)) return fail(HPT_ERR_INVALID_ARGUMENT, "%u triangles: the octant copies serve scenes of up to %u", sc->num_tris, leaf_bits ? 32u : 64u);
+    std::vector<float> nodes;
+    std::vector<uint32_t> table;
+    build_octant_copies(sc, leaf_bits != 0, nodes, table);
+    std::memcpy(nodes_out, nodes.data(), nodes.size() * sizeof(float));
+    std::memcpy(table_out, table.data(), table.size() * sizeof(uint32_t));
+    return HPT_OK;
+}
+
 int hpt_accum_clear(hpt_ctx* ctx, int64_t* accum_dev, void* stream) {
     if (!ctx || !ctx->has_scene) return fail(HPT_ERR_NO_SCENE, "no scene uploaded");
     if (int rc = set_device(ctx)) return rc;

@@ -203,6 +203,19 @@ int hpt_stats_reset(hpt_ctx* ctx);
  * reduce it across GPUs themselves */
 int hpt_accum_buffer(hpt_ctx* ctx, int64_t** accum_dev, size_t* num_elements);
 
+/* Host-only (no GPU, no context): the nine per-octant node-array copies that hpt_scene_upload
+ * derives for scenes of up to 64 triangles, for inspection and for tests of the claim they rest
+ * on (a walk over copy k reaches exactly the leaves whose boxes the ray hits, minus triangles
+ * that face away from every ray of octant k).
+ *   leaf_bits != 0: the <= 32-triangle form (leaf word = mask of the leaf's triangles),
+ *             == 0: the <= 64-triangle form (leaf word = triangle index, -1 for interior nodes)
+ *   nodes_out: float[9][num_nodes][8]  near.xyz, bits(byte offset of the miss target from the
+ *              start of the copies) | far.xyz, bits(leaf word); copy 8 = lo/hi, whole tree
+ *   table_out: uint32[32]  [k] = records in copy k; [16+2k], [17+2k] = mask of the triangles
+ *              whose back-face test octant k does not decide
+ * No counterpart in the reference. */
+int hpt_octant_copies(const hpt_scene_desc* scene, int leaf_bits, float* nodes_out, uint32_t* table_out);
+
 #ifdef __cplusplus
 }
 #endif

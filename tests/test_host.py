@@ -226,6 +226,89 @@ def test_builtin_glass_cornell_equals_the_python_definition(hp):
     assert diff == ["materials"], diff
 
 
+def _walk_octant_copy(nodes, table, k, nn, o, inv):
+    """The marking walk of the device (hpt_device.h, trace<> of the marking variants) in numpy
+    float32: returns the OR of the leaf words of the records whose box the ray hits."""
+    f32 = np.float32
+    copy = nodes[k]
+    words = copy.view(np.uint32)
+    at, stop, pending = 0, int(table[k]), 0
+    steps = 0
+    while at < stop:
+        steps += 1
+        near, far = copy[at, 0:3], copy[at, 4:7]
+        if k < 8:
+            tn = ((near - o) * inv).astype(f32).max()
+            tf = ((far - o) * inv).astype(f32).min()
+        else:
+            a, b = ((near - o) * inv).astype(f32), ((far - o) * inv).astype(f32)
+            tn, tf = np.minimum(a, b).max(), np.maximum(a, b).min()
+        if tn <= tf:
+            pending |= int(words[at, 7])
+            at += 1
+        else:
+            at = int(words[at, 3]) // 32 - k * nn
+    return pending, steps
+
+
+@pytest.mark.parametrize("scene_name", ["cornell", "glass_cornell_soup"])
+def test_octant_copies_reach_exactly_the_leaves_whose_boxes_are_hit(hp, scene_name):
+    """The per-octant trees of the marking variants (their own topology, identical boxes merged)
+    against the definition they must meet: for a ray with finite reciprocals the triangles marked
+    are those whose LEAF box passes the slab test, minus the triangles that face away from every
+    ray of the octant -- and the same set comes out of the copies built on the reference's
+    topology (HPT_OCTANT_TREES=0).  Float32 arithmetic as on the device.  No GPU needed."""
+    import os
+    from cudapathtracer_amd import scenes
+    f32 = np.float32
+    if scene_name == "cornell":
+        sc = hp.Scene.CreateBuiltinScene(hp.Scene.CornellBox, 5, 16, 16)
+    else:
+        rs = np.random.RandomState(3)
+        soup = ((rs.rand(20, 1, 3) * 400 + 80) + (rs.rand(20, 3, 3) - 0.5) * 150).astype(np.float32)
+        parts = scenes.cornell_shell_triangles() + [("soup", soup, scenes.WHITE)]
+        sc = scenes._assemble(parts, 16, 16, 5)
+    flat = sc.flat_arrays()
+    nn, nt = len(flat["nodes"]), len(flat["tris"])
+    assert nt <= 32
+    nodes, table = sc.octant_copies(True)
+    os.environ["HPT_OCTANT_TREES"] = "0"
+    try:
+        ref_nodes, ref_table = sc.octant_copies(True)
+    finally:
+        del os.environ["HPT_OCTANT_TREES"]
+    assert int(table[:8].sum()) < int(ref_table[:8].sum()), "the rebuilt copies are smaller"
+    assert np.array_equal(nodes[8], ref_nodes[8]) and table[8] == nn      # copy 8 is the reference's tree
+    leaf_of = {int(t): i for i, t in enumerate(flat["nodes"][:, 7].view(np.int32)) if t >= 0}
+    lo, hi = flat["nodes"][:, 0:3], flat["nodes"][:, 4:7]
+    nrm = flat["tris"][:, 12:15]
+    rs = np.random.RandomState(9)
+    o_all = (rs.rand(600, 3) * [556, 548, 559]).astype(f32)
+    d_all = rs.randn(600, 3).astype(f32)
+    d_all[:40] *= f32(1e-4) ** rs.randint(0, 2, (40, 3)).astype(f32)      # some nearly axis-parallel rays
+    total_new = total_ref = 0
+    for o, d in zip(o_all, d_all):
+        inv = (f32(1.0) / d).astype(f32)
+        assert np.isfinite(inv).all()
+        k = int(d[0] < 0) | int(d[1] < 0) << 1 | int(d[2] < 0) << 2
+        sgn = np.array([-1 if k & 1 else 1, -1 if k & 2 else 1, -1 if k & 4 else 1], f32)
+        want = 0
+        for t in range(nt):
+            a = nrm[t] * sgn
+            if (a >= 0).all() and (a >= 0.5).any():
+                continue                                   # rejected for every ray of the octant
+            i = leaf_of[t]
+            ta, tb = ((lo[i] - o) * inv).astype(f32), ((hi[i] - o) * inv).astype(f32)
+            if np.minimum(ta, tb).max() <= np.maximum(ta, tb).min():
+                want |= 1 << t
+        got, steps = _walk_octant_copy(nodes, table, k, nn, o, inv)
+        got_ref, steps_ref = _walk_octant_copy(ref_nodes, ref_table, k, nn, o, inv)
+        assert got == want and got_ref == want, (o, d, bin(got), bin(got_ref), bin(want))
+        total_new += steps
+        total_ref += steps_ref
+    assert total_new < 0.75 * total_ref        # and with fewer box tests
+
+
 def test_scene_errors(hp, tmp_path):
     with pytest.raises(hp.HptError):
         hp.Scene.CreateBuiltinScene(hp.Scene.CornellBox, 5, models_dir=str(tmp_path))
