@@ -347,6 +347,24 @@ HD bool box_hit_finite(const float4 lo, const float4 hi, f3 o, f3 inv) {
     return tnear <= tfar;
 }
 
+// 1. / (double)x, correctly rounded, for a float x.  The compiler's sequence for an IEEE double
+// division (v_div_scale x2, v_rcp_f64, two Newton steps, quotient, remainder, v_div_fmas,
+// v_div_fixup) with the parts left out that cannot act here: a float's magnitude lies in
+// [2^-149, 2^128), so neither operand nor quotient needs the rescaling v_div_scale / v_div_fmas
+// exist for, and v_div_fixup only rewrites the result for zero, infinite or NaN operands -- the
+// callers pass |x| >= 1e-5; an infinite or NaN x takes the plain division.
+HD double reciprocal_of_float(float x) {
+    const double d = (double)x;
+    if (!(fabsf(x) < 1.0e30f)) return 1. / d;
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    const double rem = __builtin_fma(-d, r, 1.0);  // quotient estimate q = 1.0 * r
+    return __builtin_fma(rem, r, r);
+}
+
 // Triangle::getIntersection (common/Triangle.hpp:164-198): back-face cull,
 // float cross/dot products, double det, 1/det, u, v, t.
 // kCulled: the caller has already dropped back-facing triangles.
@@ -360,7 +378,7 @@ HD bool tri_hit(const float4* __restrict__ T, int tri, f3 o, f3 d, double& t_out
     const f3 pvec = cross(d, e2);
     const float detf = dot(e1, pvec);
     if (fabsf(detf) < kEpsilon5) return false;
-    const double det_inv = 1. / (double)detf;
+    const double det_inv = reciprocal_of_float(detf);
     const f3 tvec = o - v0;
     const double u = (double)dot(tvec, pvec) * det_inv;
     if (u < 0 || u > 1) return false;
