@@ -67,8 +67,29 @@ HD float dot(f3 a, f3 b) {
     return tx + ty + tz;
 }
 HD f3 cross(f3 x, f3 y) { return mk(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y); }
-HD float length(f3 v) { return sqrtf(dot(v, v)); }
-HD f3 normalize(f3 v) { return v * (1.0f / sqrtf(dot(v, v))); }
+// Correctly rounded 1.0f / x and sqrtf(x) in fewer instructions than the compiler's general IEEE
+// sequences (which carry rescaling and fix-up steps for operands near the ends of the float
+// range).  For |x| in [1e-30, 1e30] the hardware approximation plus ONE fused correction step
+// already is the correctly rounded result: checked for every float in that range against the
+// IEEE division / square root (tools/micro/f32_exact_check.hip: 0 differ; the bare
+// approximations differ for 3.6e8 / 2.5e8 inputs).  Anything else -- zero, denormal, huge,
+// infinite, negative (sqrt), NaN -- takes the compiler's sequence.
+HD float rcp_rn(float x) {
+    const float ax = fabsf(x);
+    if (!(ax >= 1.0e-30f && ax <= 1.0e30f)) return 1.0f / x;
+    const float r = __builtin_amdgcn_rcpf(x);
+    const float e = __builtin_fmaf(-x, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+}
+HD float sqrt_rn(float x) {
+    if (!(x >= 1.0e-30f && x <= 1.0e30f)) return sqrtf(x);
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float h = 0.5f * __builtin_amdgcn_rsqf(x);
+    const float r = __builtin_fmaf(-s, s, x);
+    return __builtin_fmaf(r, h, s);
+}
+HD float length(f3 v) { return sqrt_rn(dot(v, v)); }
+HD f3 normalize(f3 v) { return v * rcp_rn(sqrt_rn(dot(v, v))); }
 HD float gmax(float x, float y) { return x > y ? x : y; }  // glm::max (external/glm/detail/func_common.inl:23-28): NaN -> y
 HD float gmin(float x, float y) { return x < y ? x : y; }  // glm::min (external/glm/detail/func_common.inl:15-19)
 HD f3 xyz(float4 v) { return mk(v.x, v.y, v.z); }
@@ -156,12 +177,12 @@ HD float portable_asin_poly(float a, float z) {
 HD float portable_acos(float x) {
     if (x > 0.5f) {
         float z = 0.5f * (1.0f - x);
-        float s = sqrtf(z);
+        float s = sqrt_rn(z);
         return 2.0f * portable_asin_poly(s, z);
     }
     if (x < -0.5f) {
         float z = 0.5f * (1.0f + x);
-        float s = sqrtf(z);
+        float s = sqrt_rn(z);
         return kPi - 2.0f * portable_asin_poly(s, z);
     }
     return 1.5707963267948966f - portable_asin_poly(x, x * x);
@@ -442,7 +463,7 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
         N = S.nodes;
         T = S.tris;
     }
-    const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // == float(1. / double(d)), Ray.hpp:21
+    const f3 inv = mk(rcp_rn(d.x), rcp_rn(d.y), rcp_rn(d.z));  // == float(1. / double(d)), Ray.hpp:21
     const bool nx = d.x < 0, ny = d.y < 0, nz = d.z < 0;
     const double limit = tmax - (double)kEpsilon4;
     int best = -1;
@@ -700,22 +721,22 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
 HD f3 local_to_world(f3 local_dir, f3 normal) {
     f3 t;
     if (fabsf(normal.x) > fabsf(normal.y)) {
-        const float inv_len = 1.0f / sqrtf(normal.x * normal.x + normal.z * normal.z);
+        const float inv_len = rcp_rn(sqrt_rn(normal.x * normal.x + normal.z * normal.z));
         t = mk(normal.z * inv_len, 0.0f, -normal.x * inv_len);
     } else {
-        const float inv_len = 1.0f / sqrtf(normal.y * normal.y + normal.z * normal.z);
+        const float inv_len = rcp_rn(sqrt_rn(normal.y * normal.y + normal.z * normal.z));
         t = mk(0.0f, normal.z * inv_len, -normal.y * inv_len);
     }
     const f3 b = cross(t, normal);
     return local_dir.x * b + local_dir.y * t + local_dir.z * normal;
 }
 HD f3 sampleHemisphereCosine(f3 n, float rx, float ry) {
-    float r = sqrtf(rx);
+    float r = sqrt_rn(rx);
     float theta = ry * kPi * 2.0f;
     float sn, cs;
     portable_sincos(theta, sn, cs);
     float dx = cs * r, dy = sn * r;
-    float z = sqrtf(1.f - (dx * dx + dy * dy));
+    float z = sqrt_rn(1.f - (dx * dx + dy * dy));
     return local_to_world(mk(dx, dy, z), n);
 }
 HD float pow5(float x) { float x2 = x * x; return x2 * x2 * x; }
@@ -748,7 +769,7 @@ HD f3 refract(f3 ray_in_dir, f3 normal, float ior) {
     const float eta = eta_i / eta_t;
     const float k = 1.0f - eta * eta * (1.0f - cos_i * cos_i);
     if (k < 0.0f) return mk(0.0f);
-    return normalize(eta * ray_in_dir + (eta * cos_i - sqrtf(k)) * correct_normal);
+    return normalize(eta * ray_in_dir + (eta * cos_i - sqrt_rn(k)) * correct_normal);
 }
 HD float fresnel(f3 observation_dir, f3 normal, float ior) {
     float cos_i = clampf(-1.0f, 1.0f, dot(observation_dir, normal));
@@ -757,9 +778,9 @@ HD float fresnel(f3 observation_dir, f3 normal, float ior) {
         eta_i = ior;
         eta_t = 1.0f;
     }
-    const float sin_t = eta_i / eta_t * sqrtf(gmax(0.0f, 1.0f - cos_i * cos_i));
+    const float sin_t = eta_i / eta_t * sqrt_rn(gmax(0.0f, 1.0f - cos_i * cos_i));
     if (sin_t >= 1.0f) return 1.0f;  // total internal reflection
-    const float cos_t = sqrtf(gmax(0.0f, 1.0f - sin_t * sin_t));
+    const float cos_t = sqrt_rn(gmax(0.0f, 1.0f - sin_t * sin_t));
     cos_i = fabsf(cos_i);
     const float rs = ((eta_t * cos_i) - (eta_i * cos_t)) / ((eta_t * cos_i) + (eta_i * cos_t));
     const float rp = ((eta_i * cos_i) - (eta_t * cos_t)) / ((eta_i * cos_i) + (eta_t * cos_t));
@@ -796,7 +817,7 @@ HD void glass_eval(float rsq, float rsq_minus_1, float roughness, float ior, f3 
     const float pm = D * andm;                                                      // pdf_micro_surface (:76-80)
     const float G = 2.0f / lerp(fabsf(2 * mds * mdo), fabsf(mds + mdo), roughness);  // geometry (:59-61)
     if (same_side) {
-        const float jac = mdo == 0.0f ? 0.0f : 1.0f / (4 * fabsf(mdo));  // reflect_jacobian (:100-102)
+        const float jac = mdo == 0.0f ? 0.0f : rcp_rn(4 * fabsf(mdo));  // reflect_jacobian (:100-102)
         pdf = pm * F * jac;
         bsdf = mk(D * F * G / 4.0f);
         return;
@@ -841,7 +862,7 @@ HD void mat_eval(const DevMaterial& m, f3 src, f3 out, f3 normal, f3& bsdf, floa
     float denominator = (ndm * ndm) * m.rsq_minus_1 + 1.0f;
     denominator = kPi * denominator * denominator;
     const float D = m.rsq / denominator;
-    const float jac = mdo == 0.0f ? 0.0f : 1.0f / (4 * fabsf(mdo));  // reflect_jacobian (:100-102)
+    const float jac = mdo == 0.0f ? 0.0f : rcp_rn(4 * fabsf(mdo));  // reflect_jacobian (:100-102)
     pdf = (D * andm) * jac;
     const float G = 2.0f / lerp(fabsf(2 * nds * ndo), fabsf(nds + ndo), m.roughness);  // geometry (:59-61)
     const f3 f0 = mk(m.f0[0], m.f0[1], m.f0[2]);
@@ -861,7 +882,7 @@ HD f3 glass_direction(f3 observation_dir, f3 micro, float ior, float r2) {
 template <bool kGlass>
 HD f3 mat_sample(const DevMaterial& m, float r0, float r1, float r2, f3 ray_out_dir, f3 normal) {
     if (m.type == 0) return sampleHemisphereCosine(normal, r0, r1);
-    const float theta = portable_acos(sqrtf((1.0f - r0) / (m.rsq_minus_1 * r0 + 1.0f)));
+    const float theta = portable_acos(sqrt_rn((1.0f - r0) / (m.rsq_minus_1 * r0 + 1.0f)));
     const float phi = 2 * kPi * r1;
     float st, ct, sp, cp;
     portable_sincos(theta, st, ct);
@@ -949,7 +970,7 @@ HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, TriQueue
                     emit_area_sum += L.area;
                     if (pick <= emit_area_sum) {
                         // BVHAccel::Sample / getSample (BVH.hpp:147-184)
-                        float q = sqrtf(u01(ra.y)) * L.root_area;
+                        float q = sqrt_rn(u01(ra.y)) * L.root_area;
                         uint32_t node = L.root_node;
                         int tri;
                         while ((tri = __float_as_int(S.nodes[2 * node + 1].w)) < 0) {
@@ -962,7 +983,7 @@ HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, TriQueue
                             }
                         }
                         // Triangle::Sample (Triangle.hpp:75-82)
-                        const float sx = sqrtf(u01(ra.z)), sy = u01(ra.w);
+                        const float sx = sqrt_rn(u01(ra.z)), sy = u01(ra.w);
                         const float4 a0 = S.tris[4 * tri], a3 = S.tris[4 * tri + 3];
                         const float4 b1 = S.tri_v12[2 * tri], b2 = S.tri_v12[2 * tri + 1];
                         lx = xyz(a0) * (1.0f - sx) + xyz(b1) * (sx * (1.0f - sy)) + xyz(b2) * (sx * sy);

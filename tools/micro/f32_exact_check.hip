@@ -1,0 +1,70 @@
+// Exhaustive search harness: which short instruction sequences give the correctly rounded
+// 1.0f / x and sqrtf(x) for EVERY float in the guarded range (others take the compiler's sequence)?
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -o f32_exact_check f32_exact_check.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+template <int kVariant>
+__device__ __forceinline__ float cand(float x) {
+    if (kVariant == 0) {  // rcp + one Newton step
+        float r = __builtin_amdgcn_rcpf(x);
+        float e = __builtin_fmaf(-x, r, 1.0f);
+        return __builtin_fmaf(e, r, r);
+    }
+    if (kVariant == 1) {  // rcp + two Newton steps
+        float r = __builtin_amdgcn_rcpf(x);
+        float e = __builtin_fmaf(-x, r, 1.0f);
+        r = __builtin_fmaf(e, r, r);
+        e = __builtin_fmaf(-x, r, 1.0f);
+        return __builtin_fmaf(e, r, r);
+    }
+    if (kVariant == 2) {  // sqrt + one residual step with 0.5 * rsq
+        float s = __builtin_amdgcn_sqrtf(x);
+        float h = 0.5f * __builtin_amdgcn_rsqf(x);
+        float r = __builtin_fmaf(-s, s, x);
+        return __builtin_fmaf(r, h, s);
+    }
+    if (kVariant == 3) {  // Goldschmidt-style from rsq
+        float r = __builtin_amdgcn_rsqf(x);
+        float g = x * r, h = 0.5f * r;
+        float e = __builtin_fmaf(-h, g, 0.5f);
+        g = __builtin_fmaf(g, e, g);
+        h = __builtin_fmaf(h, e, h);
+        float d = __builtin_fmaf(-g, g, x);
+        return __builtin_fmaf(d, h, g);
+    }
+    if (kVariant == 4) return __builtin_amdgcn_rcpf(x);   // control: the bare approximation
+    if (kVariant == 5) return __builtin_amdgcn_sqrtf(x);  // control
+    return 0.f;
+}
+template <int kVariant>
+__global__ void k(unsigned long long* bad, float lo, float hi) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    unsigned long long mine = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += stride) {
+        const float x = __uint_as_float((unsigned)i);
+        const float ax = fabsf(x);
+        if (!(ax >= lo && ax <= hi)) continue;
+        float want;
+        if (kVariant < 2 || kVariant == 4) want = 1.0f / x;
+        else { if (x < 0) continue; want = __builtin_sqrtf(x); }
+        if (__float_as_uint(cand<kVariant>(x)) != __float_as_uint(want)) ++mine;
+    }
+    if (mine) atomicAdd(bad, mine);
+}
+template <int kVariant>
+void run(const char* name, float lo, float hi) {
+    unsigned long long* bad; (void)hipMalloc(&bad, 8); (void)hipMemset(bad, 0, 8);
+    k<kVariant><<<4096, 256>>>(bad, lo, hi);
+    unsigned long long h = 0; (void)hipMemcpy(&h, bad, 8, hipMemcpyDeviceToHost);
+    printf("%-44s |x| in [%g, %g]: %llu of the floats differ from the IEEE result\n", name, lo, hi, h);
+}
+int main() {
+    run<0>("1/x: v_rcp_f32 + 1 Newton step", 1e-30f, 1e30f);
+    run<1>("1/x: v_rcp_f32 + 2 Newton steps", 1e-30f, 1e30f);
+    run<2>("sqrt: v_sqrt_f32 + residual * 0.5 rsq", 1e-30f, 1e30f);
+    run<3>("sqrt: rsq Goldschmidt + residual", 1e-30f, 1e30f);
+    run<4>("control: bare v_rcp_f32", 1e-30f, 1e30f);
+    run<5>("control: bare v_sqrt_f32", 1e-30f, 1e30f);
+    return 0;
+}
