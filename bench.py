@@ -200,13 +200,14 @@ def main():
             + closest_per_launch * FLOPS_BOUNCE
         byts = rays_per_launch * (BYTES_BOX * per_ray["box_per_ray"] + BYTES_TRI * per_ray["tri_per_ray"])
         achieved_tflops = flops / (kernel_ms * 1e-3) / 1e12
-        traffic = None
+        traffic = active_lanes = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 key = "mode%d_%dx%d_d%d_spp%d" % (args.mode, W, H, depth, spp_step)
                 traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+                active_lanes = tj.get(key, {}).get("valu_active_lane_fraction")
             except Exception:
                 traffic = None
         out = {
@@ -228,14 +229,17 @@ def main():
             "roofline": {
                 "bound": "valu", "achieved": achieved_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved_tflops / PEAK_FP32_TFLOPS, "traffic": traffic,
-                "kernel": "k_render_mega" if args.mode == 1 else "k_wf_extend+k_wf_shade",
+                "kernel": "k_render_mega" if args.mode == 1 else "k_wf_bounces",
+                "valu_active_lane_fraction": active_lanes,   # PMC, same source file as `traffic`
                 "kernel_ms": kernel_ms, "launches": launches,
                 "algorithmic_flops_per_launch": flops,
                 "algorithmic_bytes_per_launch": byts,
                 "algorithmic_GBps": byts / (kernel_ms * 1e-3) / 1e9,
                 "hbm_peak_GBps": HBM_PEAK_GBS,
-                "note": "scene (4 KiB) is LDS-resident: the kernel is VALU/divergence bound, not HBM bound; "
-                        "flops/ray = 24*box_tests + 70*tri_tests (+350 per shaded bounce), tests counted by the CPU oracle",
+                "note": ("scene is LDS-resident (20 KiB per workgroup): the kernel is VALU-issue / divergence bound, not HBM bound; "
+                         if args.scene == "cornell" else "scene records are read through L1/L2; ") +
+                        "flops/ray = 24*box_tests + 70*tri_tests (+350 per shaded bounce), tests as the reference traversal "
+                        "defines them, counted by the CPU oracle",
                 "box_tests_per_ray": per_ray["box_per_ray"], "tri_tests_per_ray": per_ray["tri_per_ray"],
             },
             "cpu_baseline": cpu,
