@@ -128,6 +128,7 @@ def _declare(L, H):
     H.hpt_host_scene_prim_ids.argtypes = [vp, vp]
     H.hpt_host_bvh_dump.argtypes = [vp, i32, C.POINTER(C.c_int), vp, vp, vp, vp]
     H.hpt_host_render.argtypes = [vp, i32, i32, i32, i32, i32, vp, C.POINTER(hpt_stats)]
+    H.hpt_host_render_iterative.argtypes = [vp, i32, i32, i32, i32, i32, vp, C.POINTER(hpt_stats)]
     H.hpt_host_save_ppm.argtypes = [C.c_char_p, vp, i32, i32]
     H.hpt_host_save_pfm.argtypes = [C.c_char_p, vp, i32, i32]
 
@@ -258,11 +259,13 @@ class Scene:
                                        m.ctypes.data))
         return dict(bounds=b, payload=p, area=a, miss=m)
 
-    def render_cpp(self, spp, max_depth, num_threads=256, mode=SingleKernel, device=0):
-        """Render through the C++ HipRenderer class (PrepareRender/Render/FinishRender)."""
+    def render_cpp(self, spp, max_depth, num_threads=256, mode=SingleKernel, device=0, iterative=False):
+        """Render through the C++ HipRenderer class: PrepareRender/Render/FinishRender, or
+        (iterative) PrepareRender, PathTrace(scene, iter) spp times, FinishRender."""
         rgb = np.zeros((self.width * self.height, 3), np.float32)
         st = hpt_stats()
-        _ckh(self._H.hpt_host_render(self._h, device, spp, max_depth, num_threads, mode, rgb.ctypes.data, C.byref(st)))
+        fn = self._H.hpt_host_render_iterative if iterative else self._H.hpt_host_render
+        _ckh(fn(self._h, device, spp, max_depth, num_threads, mode, rgb.ctypes.data, C.byref(st)))
         return rgb, st.as_dict()
 
     def close(self):
@@ -368,10 +371,23 @@ class HipRenderer:
     def __init__(self, device=0):
         self.spp = 32
         self.num_threads = 256
-        self.framebuffer = None
+        self._framebuffer = None
+        self._stale = False
         self.device = device
         self._mode = SingleKernel
         self._ctx = None
+
+    @property
+    def framebuffer(self):
+        """Renderer::framebuffer: accumulated / spp.  PathTrace only queues device work (like the
+        reference's); the download happens here, when the picture is looked at, or in FinishRender."""
+        self.RefreshFramebuffer()
+        return self._framebuffer
+
+    def RefreshFramebuffer(self):
+        if self._stale and self._ctx is not None:
+            self._framebuffer = self._ctx.resolve(max(self.spp, 1))
+            self._stale = False
 
     def SetMode(self, mode):
         if mode not in (SingleKernel, Streamed):
@@ -381,7 +397,8 @@ class HipRenderer:
     def PrepareRender(self, scene):
         self.FinishRender(scene)
         self._ctx = Context(self.device).upload(scene)
-        self.framebuffer = np.zeros((scene.width * scene.height, 3), np.float32)
+        self._framebuffer = np.zeros((scene.width * scene.height, 3), np.float32)
+        self._stale = False
 
     def Render(self, scene):
         if self._ctx is None:
@@ -389,20 +406,22 @@ class HipRenderer:
         self._ctx.accum_clear()
         if self.spp > 0:
             self._ctx.render(self._mode, self.num_threads, scene.maxDepth, 0, self.spp)
-            self.framebuffer = self._ctx.resolve(self.spp)
-        return self.framebuffer
+            self._framebuffer = self._ctx.resolve(self.spp)
+            self._stale = False
+        return self._framebuffer
 
     def PathTrace(self, scene, iter):
         if self._ctx is None:
             raise HptError("HipRenderer.PathTrace: PrepareRender has not been called")
         self._ctx.render(self._mode, self.num_threads, scene.maxDepth, iter, 1)
-        self.framebuffer = self._ctx.resolve(max(self.spp, 1))
+        self._stale = True
 
     def Stats(self):
         return self._ctx.stats() if self._ctx else {}
 
     def FinishRender(self, scene=None):
         if self._ctx is not None:
+            self.RefreshFramebuffer()
             self._ctx.close()
             self._ctx = None
 

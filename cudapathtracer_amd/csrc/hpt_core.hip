@@ -41,6 +41,7 @@ constexpr int kStatClosest = 0, kStatShadow = 1, kStatPaths = 2, kNumStats = 4;
 
 thread_local std::string g_last_error;
 
+
 int fail(int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
@@ -55,6 +56,21 @@ int fail(int code, const char* fmt, ...) {
     do {                                                                                                \
         hipError_t e_ = (expr);                                                                         \
         if (e_ != hipSuccess) return fail(HPT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// device allocation: HPT_ERR_OUT_OF_MEMORY when the device has no room, HPT_ERR_HIP otherwise
+int device_alloc(void** p, size_t bytes, const char* what) {
+    *p = nullptr;
+    const hipError_t e = hipMalloc(p, bytes ? bytes : 1);
+    if (e == hipSuccess) return HPT_OK;
+    (void)hipGetLastError();  // the failed allocation must not poison the next hipGetLastError()
+    if (e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation)
+        return fail(HPT_ERR_OUT_OF_MEMORY, "out of device memory allocating %zu bytes for %s", bytes, what);
+    return fail(HPT_ERR_HIP, "hipMalloc(%zu bytes, %s) failed: %s", bytes, what, hipGetErrorString(e));
+}
+#define ALLOC_TRY(ptr, bytes, what)                                          \
+    do {                                                                     \
+        if (int rc_ = device_alloc((void**)&(ptr), (bytes), (what))) return rc_; \
     } while (0)
 
 // ------------------------------------------------------------------ kernels --
@@ -502,6 +518,7 @@ struct hpt_ctx {
     size_t live_slots = 0;
     // timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;
+    hipStream_t last_stream = nullptr;  // stream of the most recent hpt_render
     std::vector<hipEvent_t> free_events;
     double kernel_ms = 0.0;
     uint32_t launches = 0;
@@ -561,7 +578,7 @@ int ensure_wavefront(hpt_ctx* ctx, uint64_t paths, uint32_t segments) {
             p = nullptr;
         }
                 ctx->wf_allocated = 0;
-        for (auto& p : ctx->d_wf) HIP_TRY(hipMalloc((void**)&p, paths * sizeof(float4)));
+        for (auto& p : ctx->d_wf) ALLOC_TRY(p, paths * sizeof(float4), "wavefront path queues");
         ctx->wf_allocated = paths;
     }
     const size_t want = segments;  // one live counter per segment (written by the generate kernel)
@@ -569,7 +586,7 @@ int ensure_wavefront(hpt_ctx* ctx, uint64_t paths, uint32_t segments) {
         (void)hipFree(ctx->d_live);
         ctx->d_live = nullptr;
         ctx->live_slots = 0;
-        HIP_TRY(hipMalloc((void**)&ctx->d_live, want * sizeof(uint32_t)));
+        ALLOC_TRY(ctx->d_live, want * sizeof(uint32_t), "live");
         ctx->live_slots = want;
     }
     return HPT_OK;
@@ -874,27 +891,41 @@ void build_octant_copies(const hpt_scene_desc* sc, bool leaf_bits, std::vector<f
     }
 }
 
-hipEvent_t take_event(hpt_ctx* ctx) {
+// Timing events: a render takes a pair from the free list, records it around its launches and
+// parks it in `pending_events`; pairs whose second event has completed are read and recycled by
+// the next hpt_render (no host wait), so a loop of renders that never reads the statistics holds
+// a bounded number of events.
+int take_event(hpt_ctx* ctx, hipEvent_t* out) {
     if (!ctx->free_events.empty()) {
-        hipEvent_t e = ctx->free_events.back();
+        *out = ctx->free_events.back();
         ctx->free_events.pop_back();
-        return e;
+        return HPT_OK;
     }
-    hipEvent_t e = nullptr;
-    (void)hipEventCreate(&e);
-    return e;
+    HIP_TRY(hipEventCreate(out));
+    return HPT_OK;
 }
 
-int settle_events(hpt_ctx* ctx) {
+constexpr size_t kMaxPendingEvents = 64;  // pairs; beyond that hpt_render waits for the oldest
+
+// settle the pairs at the front of the list that have completed (all of them with wait = true)
+int settle_events(hpt_ctx* ctx, bool wait) {
+    size_t done = 0;
     for (auto& pr : ctx->pending_events) {
-        HIP_TRY(hipEventSynchronize(pr.second));
+        if (wait || ctx->pending_events.size() - done > kMaxPendingEvents) {
+            HIP_TRY(hipEventSynchronize(pr.second));
+        } else {
+            const hipError_t q = hipEventQuery(pr.second);
+            if (q == hipErrorNotReady) break;
+            if (q != hipSuccess) return fail(HPT_ERR_HIP, "hipEventQuery failed: %s", hipGetErrorString(q));
+        }
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
         ctx->kernel_ms += ms;
         ctx->free_events.push_back(pr.first);
         ctx->free_events.push_back(pr.second);
+        ++done;
     }
-    ctx->pending_events.clear();
+    ctx->pending_events.erase(ctx->pending_events.begin(), ctx->pending_events.begin() + (long)done);
     return HPT_OK;
 }
 
@@ -913,6 +944,139 @@ int grid_for(const hpt_ctx* ctx, uint64_t work, int block) {
     const uint64_t per_cu = 2048ull / (uint64_t)(block < 64 ? 64 : block);
     const uint64_t cap = (uint64_t)ctx->num_cus * (per_cu ? per_cu : 1ull) * 2ull;
     return (int)(want < cap ? (want ? want : 1) : cap);
+}
+
+// Buffers a render needs beyond its inputs and outputs.  nullptr for `fixed` in render_launch =
+// the context's own (the wavefront queues grow on demand); otherwise exactly these are used and
+// nothing is allocated.
+struct RenderBuffers {
+    uint32_t* unit_counter;  // work-unit counter of the single-kernel mode
+    float4* wf[8];           // two wavefront queues of four planes each
+    uint64_t wf_paths;       // records each plane holds
+    uint32_t* live;          // per-segment live counters
+    size_t live_slots;
+};
+
+int check_render_args(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sample_begin, uint32_t sample_count) {
+    if (!ctx || !ctx->has_scene) return fail(HPT_ERR_NO_SCENE, "no scene uploaded");
+    if (mode != HPT_MODE_SINGLE_KERNEL && mode != HPT_MODE_STREAMED) return fail(HPT_ERR_INVALID_ARGUMENT, "mode must be 1 or 2, got %d", mode);
+    if (block < 1 || block > 1024) return fail(HPT_ERR_INVALID_ARGUMENT, "block size %d not in [1, 1024]", block);
+    if (max_depth < 0 || max_depth > 16384) return fail(HPT_ERR_INVALID_ARGUMENT, "max_depth %d not in [0, 16384]", max_depth);
+    if ((uint64_t)sample_begin + sample_count > 0xFFFFFFFFull) return fail(HPT_ERR_INVALID_ARGUMENT, "sample range overflows 32 bits");
+    return HPT_OK;
+}
+
+// the kernel launches of one render request (arguments already checked, device current)
+int render_launch(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sample_begin, uint32_t sample_count,
+                  int64_t* accum, hipStream_t stream, const RenderBuffers* fixed, uint32_t* launches_out) {
+    uint32_t* const unit_counter = fixed ? fixed->unit_counter : ctx->d_unit_counter;
+    const DevScene& S = ctx->S;
+    const uint32_t tiles = (((uint32_t)S.width + 7u) >> 3) * (((uint32_t)S.height + 7u) >> 3);
+    const uint64_t lanes = (uint64_t)tiles * 64ull;  // lanes per sample (edge tiles are partly idle)
+    const uint32_t lds = lds_bytes(S, 0);  // scene only; queues are added per launch below
+
+    // A workgroup stages the scene in LDS for itself (variants 1, 2, 3, 6: 20 KiB for the Cornell
+    // box), so small workgroups leave most of a CU's wave slots empty (64 lanes: half the speed of
+    // 256).  No result depends on the workgroup size, so such scenes are run with at least 256
+    // lanes per workgroup; HPT_EXACT_BLOCK=1 keeps the size asked for.
+    if (S.lds_float4s > 0 && block < 256) {
+        const char* e = getenv("HPT_EXACT_BLOCK");
+        if (!(e && atoi(e) != 0)) block = 256;
+    }
+
+    uint32_t launches = 0;
+
+    if (mode == HPT_MODE_SINGLE_KERNEL) {
+        const uint32_t waves_per_block = ((uint32_t)block + 63u) >> 6;
+        uint32_t lds_mega = lds + waves_per_block * 384u * 8u + (lds_bytes(S, block) - lds);  // + two tile accumulators per wave + queues
+#ifdef HPT_PROFILE
+        lds_mega += waves_per_block * 3u * kProfSections * 8u;
+#endif
+        // per-lane ray counters are 16 bits wide and are emptied when a wave opens a unit; while a
+        // pool is not empty the wave's 64 lanes all advance, so between two openings a wave runs at
+        // most (c + 2) * max_depth loop iterations for units of c samples
+        const uint32_t cap = 65535u / (uint32_t)max_depth;
+        const uint32_t chunk = std::max(1u, std::min(ctx->spp_per_unit, cap > 2u ? cap - 2u : 1u));
+        // at most 2^22 units per launch
+        const uint32_t max_chunks = std::max(1u, (1u << 22) / tiles);
+        // launches of about 2^28 paths (256 spp at 1024x1024: ~0.25 s on the Cornell box) amortise the
+        // launch's tail without running one kernel for many seconds on heavy scenes
+        const uint32_t want = ctx->spp_per_launch ? ctx->spp_per_launch : std::max(1u, (1u << 22) / tiles);
+        const uint32_t per_launch = std::max(1u, std::min(want, chunk * max_chunks));
+        // persistent waves: as many workgroups as are resident at once
+        if (lds_mega > kMaxLdsPerBlock)
+            return fail(HPT_ERR_INVALID_ARGUMENT, "a workgroup of %d lanes needs %u bytes of LDS for this scene (limit %u): use a smaller block", block, lds_mega, kMaxLdsPerBlock);
+        int per_cu = 0;
+        HPT_DISPATCH_RENDER(S.variant, ctx->has_glass, {
+            if (block <= 256) {
+                if (lds_mega > 48u * 1024u) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render_mega<kS, kG, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mega));
+                HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_mega<kS, kG, 256>, block, lds_mega));
+            } else {
+                if (lds_mega > 48u * 1024u) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render_mega<kS, kG, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mega));
+                HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_mega<kS, kG, 1024>, block, lds_mega));
+            }
+        })
+        if (per_cu < 1) return fail(HPT_ERR_INVALID_ARGUMENT, "a workgroup of %d lanes with %u bytes of LDS does not fit a compute unit", block, lds_mega);
+        const uint32_t resident = (uint32_t)per_cu * (uint32_t)ctx->num_cus;
+        for (uint32_t s = sample_begin; s < sample_begin + sample_count;) {
+            const uint32_t n = (sample_begin + sample_count - s > per_launch) ? per_launch : sample_begin + sample_count - s;
+            const uint32_t units = tiles * ((n + chunk - 1u) / chunk);
+            const uint32_t blocks = std::min(resident, (units + waves_per_block - 1u) / waves_per_block);
+            HIP_TRY(hipMemsetAsync(unit_counter, 0, sizeof(uint32_t), stream));
+            HPT_DISPATCH_RENDER(S.variant, ctx->has_glass, {
+                if (block <= 256) hipLaunchKernelGGL((k_render_mega<kS, kG, 256>), dim3(blocks), dim3(block), lds_mega, stream, S, max_depth, s, n, chunk, units, accum, ctx->d_stats, unit_counter);
+                else hipLaunchKernelGGL((k_render_mega<kS, kG, 1024>), dim3(blocks), dim3(block), lds_mega, stream, S, max_depth, s, n, chunk, units, accum, ctx->d_stats, unit_counter);
+            })
+            HIP_TRY(hipGetLastError());
+            ++launches;
+            s += n;
+        }
+    } else {
+        // the wavefront kernels are built for workgroups of up to 256 lanes
+        const int wblock = block > 256 ? 256 : block;
+        const uint64_t total = lanes * (uint64_t)sample_count;
+        const uint64_t cap_limit = fixed ? fixed->wf_paths : ctx->wf_capacity;
+        const uint64_t cap = cap_limit < total ? cap_limit : ((total + 63ull) & ~63ull);
+        // one queue segment per workgroup; exactly the workgroups that are resident at once
+        int per_cu = 0;
+        HPT_DISPATCH_RENDER(S.variant, ctx->has_glass, {
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_bounces<kS, kG>, wblock, lds_bytes(S, wblock)));
+        })
+        if (per_cu < 1) return fail(HPT_ERR_INVALID_ARGUMENT, "the wavefront kernel does not fit a compute unit with %u bytes of LDS", lds_bytes(S, wblock));
+        const uint64_t cap_groups = (cap + 63ull) >> 6;
+        uint32_t segments = (uint32_t)std::min<uint64_t>((uint64_t)per_cu * (uint64_t)ctx->num_cus, cap_groups);
+        if (fixed) segments = (uint32_t)std::min<uint64_t>(segments, fixed->live_slots);
+        uint32_t seg = (uint32_t)((cap_groups + segments - 1ull) / segments) * 64u;  // records per segment
+        float4* const* wf = ctx->d_wf;
+        uint32_t* live = nullptr;
+        if (fixed) {
+            // fixed buffers: whole segments must fit (rounding each segment up to 64 records can
+            // take the batch past the buffer: then the segments shrink and the batch with them)
+            if ((uint64_t)seg * segments > fixed->wf_paths) seg = (uint32_t)(fixed->wf_paths / segments) & ~63u;
+            if (seg == 0) return fail(HPT_ERR_TOO_LARGE, "the fixed path queues (%llu records) are too small for %u segments", (unsigned long long)fixed->wf_paths, segments);
+            wf = fixed->wf;
+            live = fixed->live;
+        } else {
+            if (int rc = ensure_wavefront(ctx, (uint64_t)seg * segments, segments)) return rc;
+            live = ctx->d_live;
+        }
+        const uint64_t batch = std::min<uint64_t>(cap, (uint64_t)seg * segments);  // paths per generate + bounces pair
+        WfQueue q[2] = {{wf[0], wf[1], wf[2], wf[3]}, {wf[4], wf[5], wf[6], wf[7]}};
+        // the generate kernel needs whole waves
+        const int gblock = (wblock + 63) & ~63;
+        for (uint64_t first = 0; first < total; first += batch) {
+            const uint32_t count = (uint32_t)((total - first < batch) ? total - first : batch);
+            hipLaunchKernelGGL(k_wf_generate, dim3(segments), dim3(gblock), 0, stream, S, sample_begin, first, count, (uint32_t)lanes, seg, q[0], live, ctx->d_stats);
+            HIP_TRY(hipGetLastError());
+            HPT_DISPATCH_RENDER(S.variant, ctx->has_glass, {
+                hipLaunchKernelGGL((k_wf_bounces<kS, kG>), dim3(segments), dim3(wblock), lds_bytes(S, wblock), stream, S, max_depth, seg, q[0], q[1], live, accum, ctx->d_stats);
+            })
+            HIP_TRY(hipGetLastError());
+            launches += 2;
+        }
+    }
+    *launches_out = launches;
+    return HPT_OK;
 }
 
 }  // namespace
@@ -969,7 +1133,7 @@ int hpt_context_destroy(hpt_ctx* ctx) {
     if (!ctx) return HPT_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    (void)settle_events(ctx);
+    (void)settle_events(ctx, true);
     for (hipEvent_t e : ctx->free_events) (void)hipEventDestroy(e);
     free_scene(ctx);
     free_wavefront(ctx);
@@ -986,12 +1150,12 @@ int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* sc) {
     HIP_TRY(hipDeviceSynchronize());
     free_scene(ctx);
     const size_t nn = sc->num_nodes, nt = sc->num_tris;
-    HIP_TRY(hipMalloc((void**)&ctx->d_nodes, nn * 32));
-    HIP_TRY(hipMalloc((void**)&ctx->d_node_area, nn * 4));
-    HIP_TRY(hipMalloc((void**)&ctx->d_tris, nt * 64));
-    HIP_TRY(hipMalloc((void**)&ctx->d_tri_v12, nt * 32));
-    HIP_TRY(hipMalloc((void**)&ctx->d_mats, sc->num_materials * sizeof(DevMaterial)));
-    HIP_TRY(hipMalloc((void**)&ctx->d_lights, (sc->num_lights ? sc->num_lights : 1) * sizeof(DevLight)));
+    ALLOC_TRY(ctx->d_nodes, nn * 32, "nodes");
+    ALLOC_TRY(ctx->d_node_area, nn * 4, "node_area");
+    ALLOC_TRY(ctx->d_tris, nt * 64, "tris");
+    ALLOC_TRY(ctx->d_tri_v12, nt * 32, "tri_v12");
+    ALLOC_TRY(ctx->d_mats, sc->num_materials * sizeof(DevMaterial), "mats");
+    ALLOC_TRY(ctx->d_lights, (sc->num_lights ? sc->num_lights : 1) * sizeof(DevLight), "lights");
     HIP_TRY(hipMemcpy(ctx->d_nodes, sc->nodes, nn * 32, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->d_node_area, sc->node_area, nn * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->d_tri_v12, sc->tri_v12, nt * 32, hipMemcpyHostToDevice));
@@ -1105,14 +1269,14 @@ int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* sc) {
             }
             stack_depth = std::max(1u, need[0]);
             stack_depth_any = std::max(1u, need_any[0]);
-            HIP_TRY(hipMalloc((void**)&ctx->d_pairs, rec.size() * 4));
+            ALLOC_TRY(ctx->d_pairs, rec.size() * 4, "pairs");
             HIP_TRY(hipMemcpy(ctx->d_pairs, rec.data(), rec.size() * 4, hipMemcpyHostToDevice));
         }
     }
     ctx->accum_elems = 3ull * (size_t)sc->width * (size_t)sc->height;
-    HIP_TRY(hipMalloc((void**)&ctx->d_accum, ctx->accum_elems * sizeof(int64_t)));
+    ALLOC_TRY(ctx->d_accum, ctx->accum_elems * sizeof(int64_t), "accum");
     HIP_TRY(hipMemset(ctx->d_accum, 0, ctx->accum_elems * sizeof(int64_t)));
-    HIP_TRY(hipMalloc((void**)&ctx->d_rgb, ctx->accum_elems * sizeof(float)));
+    ALLOC_TRY(ctx->d_rgb, ctx->accum_elems * sizeof(float), "rgb");
 
     DevScene& S = ctx->S;
     const uint32_t seed = S.seed;
@@ -1181,8 +1345,8 @@ int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* sc) {
         std::vector<float> oct_nodes;
         std::vector<uint32_t> oct_table;
         build_octant_copies(sc, S.variant == kSceneTiny32, oct_nodes, oct_table);
-        HIP_TRY(hipMalloc((void**)&ctx->d_oct_nodes, oct_nodes.size() * 4));
-        HIP_TRY(hipMalloc((void**)&ctx->d_oct_table, oct_table.size() * 4));
+        ALLOC_TRY(ctx->d_oct_nodes, oct_nodes.size() * 4, "oct_nodes");
+        ALLOC_TRY(ctx->d_oct_table, oct_table.size() * 4, "oct_table");
         HIP_TRY(hipMemcpy(ctx->d_oct_nodes, oct_nodes.data(), oct_nodes.size() * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(ctx->d_oct_table, oct_table.data(), oct_table.size() * 4, hipMemcpyHostToDevice));
         S.oct_nodes = ctx->d_oct_nodes;
@@ -1248,108 +1412,33 @@ int hpt_accum_clear(hpt_ctx* ctx, int64_t* accum_dev, void* stream) {
 
 int hpt_render(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sample_begin, uint32_t sample_count,
                int64_t* accum_dev, void* stream_) {
-    if (!ctx || !ctx->has_scene) return fail(HPT_ERR_NO_SCENE, "no scene uploaded");
-    if (mode != HPT_MODE_SINGLE_KERNEL && mode != HPT_MODE_STREAMED) return fail(HPT_ERR_INVALID_ARGUMENT, "mode must be 1 or 2, got %d", mode);
-    if (block < 1 || block > 1024) return fail(HPT_ERR_INVALID_ARGUMENT, "block size %d not in [1, 1024]", block);
-    if (max_depth < 0 || max_depth > 16384) return fail(HPT_ERR_INVALID_ARGUMENT, "max_depth %d not in [0, 16384]", max_depth);
-    if ((uint64_t)sample_begin + sample_count > 0xFFFFFFFFull) return fail(HPT_ERR_INVALID_ARGUMENT, "sample range overflows 32 bits");
+    if (int rc = check_render_args(ctx, mode, block, max_depth, sample_begin, sample_count)) return rc;
     if (int rc = set_device(ctx)) return rc;
     hipStream_t stream = (hipStream_t)stream_;
-    int64_t* accum = accum_dev ? accum_dev : ctx->d_accum;
     if (sample_count == 0 || max_depth == 0) return HPT_OK;  // castRay's loop body never runs: radiance 0
-    const DevScene& S = ctx->S;
-    const uint32_t tiles = (((uint32_t)S.width + 7u) >> 3) * (((uint32_t)S.height + 7u) >> 3);
-    const uint64_t lanes = (uint64_t)tiles * 64ull;  // lanes per sample (edge tiles are partly idle)
-    const uint32_t lds = lds_bytes(S, 0);  // scene only; queues are added per launch below
-
-    // A workgroup stages the scene in LDS for itself (variants 1, 2, 3, 6: 20 KiB for the Cornell
-    // box), so small workgroups leave most of a CU's wave slots empty (64 lanes: half the speed of
-    // 256).  No result depends on the workgroup size, so such scenes are run with at least 256
-    // lanes per workgroup; HPT_EXACT_BLOCK=1 keeps the size asked for.
-    if (S.lds_float4s > 0 && block < 256) {
-        const char* e = getenv("HPT_EXACT_BLOCK");
-        if (!(e && atoi(e) != 0)) block = 256;
+    if (int rc = settle_events(ctx, false)) return rc;
+    // The unit counter and the wavefront queues belong to the context: a render on another stream
+    // than the previous one waits for it instead of racing with it.
+    if (!ctx->pending_events.empty() && ctx->last_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, ctx->pending_events.back().second, 0));
+    ctx->last_stream = stream;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (int rc = take_event(ctx, &ev0)) return rc;
+    if (int rc = take_event(ctx, &ev1)) {
+        ctx->free_events.push_back(ev0);
+        return rc;
     }
-
-    hipEvent_t ev0 = take_event(ctx), ev1 = take_event(ctx);
-    HIP_TRY(hipEventRecord(ev0, stream));
     uint32_t launches = 0;
-
-    if (mode == HPT_MODE_SINGLE_KERNEL) {
-        const uint32_t waves_per_block = ((uint32_t)block + 63u) >> 6;
-        uint32_t lds_mega = lds + waves_per_block * 384u * 8u + (lds_bytes(S, block) - lds);  // + two tile accumulators per wave + queues
-#ifdef HPT_PROFILE
-        lds_mega += waves_per_block * 3u * kProfSections * 8u;
-#endif
-        // per-lane ray counters are 16 bits wide and are emptied when a wave opens a unit; while a
-        // pool is not empty the wave's 64 lanes all advance, so between two openings a wave runs at
-        // most (c + 2) * max_depth loop iterations for units of c samples
-        const uint32_t cap = 65535u / (uint32_t)max_depth;
-        const uint32_t chunk = std::max(1u, std::min(ctx->spp_per_unit, cap > 2u ? cap - 2u : 1u));
-        // at most 2^22 units per launch
-        const uint32_t max_chunks = std::max(1u, (1u << 22) / tiles);
-        // launches of about 2^28 paths (256 spp at 1024x1024: ~0.25 s on the Cornell box) amortise the
-        // launch's tail without running one kernel for many seconds on heavy scenes
-        const uint32_t want = ctx->spp_per_launch ? ctx->spp_per_launch : std::max(1u, (1u << 22) / tiles);
-        const uint32_t per_launch = std::max(1u, std::min(want, chunk * max_chunks));
-        // persistent waves: as many workgroups as are resident at once
-        if (lds_mega > kMaxLdsPerBlock)
-            return fail(HPT_ERR_INVALID_ARGUMENT, "a workgroup of %d lanes needs %u bytes of LDS for this scene (limit %u): use a smaller block", block, lds_mega, kMaxLdsPerBlock);
-        int per_cu = 0;
-        HPT_DISPATCH_RENDER(S.variant, ctx->has_glass, {
-            if (block <= 256) {
-                if (lds_mega > 48u * 1024u) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render_mega<kS, kG, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mega));
-                HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_mega<kS, kG, 256>, block, lds_mega));
-            } else {
-                if (lds_mega > 48u * 1024u) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render_mega<kS, kG, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mega));
-                HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_mega<kS, kG, 1024>, block, lds_mega));
-            }
-        })
-        if (per_cu < 1) return fail(HPT_ERR_INVALID_ARGUMENT, "a workgroup of %d lanes with %u bytes of LDS does not fit a compute unit", block, lds_mega);
-        const uint32_t resident = (uint32_t)per_cu * (uint32_t)ctx->num_cus;
-        for (uint32_t s = sample_begin; s < sample_begin + sample_count;) {
-            const uint32_t n = (sample_begin + sample_count - s > per_launch) ? per_launch : sample_begin + sample_count - s;
-            const uint32_t units = tiles * ((n + chunk - 1u) / chunk);
-            const uint32_t blocks = std::min(resident, (units + waves_per_block - 1u) / waves_per_block);
-            HIP_TRY(hipMemsetAsync(ctx->d_unit_counter, 0, sizeof(uint32_t), stream));
-            HPT_DISPATCH_RENDER(S.variant, ctx->has_glass, {
-                if (block <= 256) hipLaunchKernelGGL((k_render_mega<kS, kG, 256>), dim3(blocks), dim3(block), lds_mega, stream, S, max_depth, s, n, chunk, units, accum, ctx->d_stats, ctx->d_unit_counter);
-                else hipLaunchKernelGGL((k_render_mega<kS, kG, 1024>), dim3(blocks), dim3(block), lds_mega, stream, S, max_depth, s, n, chunk, units, accum, ctx->d_stats, ctx->d_unit_counter);
-            })
-            HIP_TRY(hipGetLastError());
-            ++launches;
-            s += n;
-        }
-    } else {
-        // the wavefront kernels are built for workgroups of up to 256 lanes
-        const int wblock = block > 256 ? 256 : block;
-        const uint64_t total = lanes * (uint64_t)sample_count;
-        const uint64_t cap = ctx->wf_capacity < total ? ctx->wf_capacity : ((total + 63ull) & ~63ull);
-        // one queue segment per workgroup; exactly the workgroups that are resident at once
-        int per_cu = 0;
-        HPT_DISPATCH_RENDER(S.variant, ctx->has_glass, {
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_bounces<kS, kG>, wblock, lds_bytes(S, wblock)));
-        })
-        if (per_cu < 1) return fail(HPT_ERR_INVALID_ARGUMENT, "the wavefront kernel does not fit a compute unit with %u bytes of LDS", lds_bytes(S, wblock));
-        const uint64_t cap_groups = (cap + 63ull) >> 6;
-        const uint32_t segments = (uint32_t)std::min<uint64_t>((uint64_t)per_cu * (uint64_t)ctx->num_cus, cap_groups);
-        const uint32_t seg = (uint32_t)((cap_groups + segments - 1ull) / segments) * 64u;  // records per segment
-        if (int rc = ensure_wavefront(ctx, (uint64_t)seg * segments, segments)) return rc;
-        WfQueue q[2] = {{ctx->d_wf[0], ctx->d_wf[1], ctx->d_wf[2], ctx->d_wf[3]}, {ctx->d_wf[4], ctx->d_wf[5], ctx->d_wf[6], ctx->d_wf[7]}};
-        // the generate kernel needs whole waves
-        const int gblock = (wblock + 63) & ~63;
-        for (uint64_t first = 0; first < total; first += cap) {
-            const uint32_t count = (uint32_t)((total - first < cap) ? total - first : cap);
-            hipLaunchKernelGGL(k_wf_generate, dim3(segments), dim3(gblock), 0, stream, S, sample_begin, first, count, (uint32_t)lanes, seg, q[0], ctx->d_live, ctx->d_stats);
-            HIP_TRY(hipGetLastError());
-            HPT_DISPATCH_RENDER(S.variant, ctx->has_glass, {
-                hipLaunchKernelGGL((k_wf_bounces<kS, kG>), dim3(segments), dim3(wblock), lds_bytes(S, wblock), stream, S, max_depth, seg, q[0], q[1], ctx->d_live, accum, ctx->d_stats);
-            })
-            HIP_TRY(hipGetLastError());
-            launches += 2;
-        }
+    int rc = HPT_OK;
+    hipError_t e = hipEventRecord(ev0, stream);
+    if (e == hipSuccess) {
+        rc = render_launch(ctx, mode, block, max_depth, sample_begin, sample_count, accum_dev ? accum_dev : ctx->d_accum, stream, nullptr, &launches);
+        if (rc == HPT_OK) e = hipEventRecord(ev1, stream);
     }
-    HIP_TRY(hipEventRecord(ev1, stream));
+    if (rc != HPT_OK || e != hipSuccess) {
+        ctx->free_events.push_back(ev0);
+        ctx->free_events.push_back(ev1);
+        return rc != HPT_OK ? rc : fail(HPT_ERR_HIP, "hipEventRecord failed: %s", hipGetErrorString(e));
+    }
     ctx->pending_events.emplace_back(ev0, ev1);
     ctx->launches += launches;
     return HPT_OK;
@@ -1414,15 +1503,19 @@ int hpt_intersect_batch(hpt_ctx* ctx, size_t n, const float* o, const float* d, 
         hipError_t e_ = (expr);                                                                         \
         if (e_ != hipSuccess) { cleanup(); return fail(HPT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } \
     } while (0)
-    TRY_OR_CLEAN(hipMalloc((void**)&d_o, n * 12));
-    TRY_OR_CLEAN(hipMalloc((void**)&d_d, n * 12));
-    TRY_OR_CLEAN(hipMalloc((void**)&d_p, n * 4));
-    TRY_OR_CLEAN(hipMalloc((void**)&d_t, n * 8));
+#define ALLOC_OR_CLEAN(ptr, bytes)                                              \
+    do {                                                                        \
+        if (int rc_ = device_alloc((void**)&(ptr), (bytes), "ray batch staging")) { cleanup(); return rc_; } \
+    } while (0)
+    ALLOC_OR_CLEAN(d_o, n * 12);
+    ALLOC_OR_CLEAN(d_d, n * 12);
+    ALLOC_OR_CLEAN(d_p, n * 4);
+    ALLOC_OR_CLEAN(d_t, n * 8);
     TRY_OR_CLEAN(hipMemcpy(d_o, o, n * 12, hipMemcpyHostToDevice));
     TRY_OR_CLEAN(hipMemcpy(d_d, d, n * 12, hipMemcpyHostToDevice));
     if (shadow) {
-        TRY_OR_CLEAN(hipMalloc((void**)&d_s, n));
-        TRY_OR_CLEAN(hipMalloc((void**)&d_tm, n * 8));
+        ALLOC_OR_CLEAN(d_s, n);
+        ALLOC_OR_CLEAN(d_tm, n * 8);
         TRY_OR_CLEAN(hipMemcpy(d_s, shadow, n, hipMemcpyHostToDevice));
         TRY_OR_CLEAN(hipMemcpy(d_tm, tmax, n * 8, hipMemcpyHostToDevice));
     }
@@ -1433,6 +1526,7 @@ int hpt_intersect_batch(hpt_ctx* ctx, size_t n, const float* o, const float* d, 
         TRY_OR_CLEAN(hipMemcpy(t, d_t, n * 8, hipMemcpyDeviceToHost));
     }
 #undef TRY_OR_CLEAN
+#undef ALLOC_OR_CLEAN
     cleanup();
     return rc;
 }
@@ -1441,7 +1535,7 @@ int hpt_stats_get(hpt_ctx* ctx, hpt_stats* out) {
     if (!ctx || !out) return fail(HPT_ERR_INVALID_ARGUMENT, "null argument");
     if (int rc = set_device(ctx)) return rc;
     HIP_TRY(hipDeviceSynchronize());
-    if (int rc = settle_events(ctx)) return rc;
+    if (int rc = settle_events(ctx, true)) return rc;
     unsigned long long h[kNumStats];
     HIP_TRY(hipMemcpy(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost));
     std::memset(out, 0, sizeof *out);
@@ -1468,7 +1562,7 @@ int hpt_stats_reset(hpt_ctx* ctx) {
     if (!ctx) return fail(HPT_ERR_INVALID_ARGUMENT, "ctx is null");
     if (int rc = set_device(ctx)) return rc;
     HIP_TRY(hipDeviceSynchronize());
-    if (int rc = settle_events(ctx)) return rc;
+    if (int rc = settle_events(ctx, true)) return rc;
     HIP_TRY(hipMemset(ctx->d_stats, 0, kNumStats * sizeof(unsigned long long)));
     ctx->kernel_ms = 0.0;
     ctx->launches = 0;

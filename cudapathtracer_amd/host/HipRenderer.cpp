@@ -29,13 +29,25 @@ void HipRenderer::PrepareRender(const Scene& scene) {
     const hpt_scene_desc desc = scene.describe();
     check(hpt_scene_upload(ctx, &desc), "hpt_scene_upload");
     framebuffer.assign(num_pixels, Vec3(0.f));
+    framebuffer_stale = false;
     next_sample = 0;
 }
 
 // CudaRenderer::FinishRender (gpu_path_tracer/CudaRenderer.cu:37-49)
 void HipRenderer::FinishRender(const Scene&) {
-    if (ctx) check(hpt_context_destroy(ctx), "hpt_context_destroy");
+    if (ctx) {
+        RefreshFramebuffer();  // samples added by PathTrace since the last download
+        check(hpt_context_destroy(ctx), "hpt_context_destroy");
+    }
     ctx = nullptr;
+}
+
+// accumulators -> framebuffer (accumulated / spp), only when PathTrace has added samples since
+// the last download
+void HipRenderer::RefreshFramebuffer() {
+    if (!ctx || !framebuffer_stale) return;
+    check(hpt_resolve(ctx, nullptr, (uint32_t)(this->spp > 0 ? this->spp : 1), &framebuffer[0].x, nullptr), "hpt_resolve");
+    framebuffer_stale = false;
 }
 
 // clear, trace spp samples per pixel, download (CudaRenderer::Render,
@@ -51,6 +63,7 @@ void HipRenderer::Render(const Scene& scene) {
             next_sample = (unsigned)this->spp;
             static_assert(sizeof(Vec3) == 3 * sizeof(float), "Vec3 must be three packed floats");
             check(hpt_resolve(ctx, nullptr, (uint32_t)this->spp, &framebuffer[0].x, nullptr), "hpt_resolve");
+            framebuffer_stale = false;
         }
     }
     auto stop = std::chrono::system_clock::now();
@@ -62,13 +75,15 @@ void HipRenderer::Render(const Scene& scene) {
 }
 
 // CudaRenderer::PathTrace (gpu_path_tracer/CudaRenderer.cu:76-94): one sample
-// per pixel with sample index `iter`, added to the device accumulators.  The
-// framebuffer is refreshed as accumulated / spp, as the reference's running
-// `+= L / spp` would hold it after the same calls.
+// per pixel with sample index `iter`, added to the device accumulators.  Like
+// the reference's, it only queues device work: nothing is copied to the host.
+// `framebuffer` is brought up to date (accumulated / spp, what the reference's
+// running `+= L / spp` holds after the same calls) by RefreshFramebuffer() or
+// FinishRender().
 void HipRenderer::PathTrace(const Scene& scene, int iter) {
     if (!ctx) throw std::runtime_error("HipRenderer::PathTrace: PrepareRender has not been called");
     check(hpt_render(ctx, (int)mode, num_threads, scene.maxDepth, (uint32_t)iter, 1u, nullptr, nullptr), "hpt_render");
-    check(hpt_resolve(ctx, nullptr, (uint32_t)(this->spp > 0 ? this->spp : 1), &framebuffer[0].x, nullptr), "hpt_resolve");
+    framebuffer_stale = true;
 }
 
 hpt_stats HipRenderer::Stats() {

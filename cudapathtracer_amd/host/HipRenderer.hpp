@@ -15,6 +15,7 @@ private:
     hpt_ctx* ctx = nullptr;
     int num_pixels = 0;
     unsigned next_sample = 0;
+    bool framebuffer_stale = false;  // PathTrace has added samples that `framebuffer` does not show yet
 
 public:
     int num_threads = 256;
@@ -29,8 +30,12 @@ public:
     void FinishRender(const Scene& scene);
 
     // one more sample per pixel (sample index = iter), accumulated on the device;
-    // call it many times to reach the targeted spp
+    // call it many times to reach the targeted spp.  Queues device work only.
     void PathTrace(const Scene& scene, int iter);
+    // download accumulated / spp into `framebuffer` if PathTrace has run since the last download
+    // (FinishRender does it too); no counterpart in the reference, whose PathTrace callers have
+    // no way to see the picture before Render's own copy
+    void RefreshFramebuffer();
 
     // ray counters and kernel time since PrepareRender
     hpt_stats Stats();

@@ -182,6 +182,26 @@ int hpt_host_render(const hpt_host_scene* s, int device, int spp, int max_depth,
     })
 }
 
+int hpt_host_render_iterative(const hpt_host_scene* s, int device, int spp, int max_depth, int num_threads, int mode,
+                              float* rgb, hpt_stats* stats) {
+    if (!s || !rgb) return fail("null argument");
+    if (mode != 1 && mode != 2) return fail("mode must be 1 (SingleKernel) or 2 (Streamed)");
+    GUARD({
+        Scene sc = s->scene;
+        sc.maxDepth = max_depth;
+        HipRenderer r;
+        r.spp = spp;
+        r.device = device;
+        r.SetMode((HipRenderMode)mode);
+        r.num_threads = num_threads;
+        r.PrepareRender(sc);
+        for (int iter = 0; iter < spp; ++iter) r.PathTrace(sc, iter);
+        if (stats) *stats = r.Stats();
+        r.FinishRender(sc);  // downloads accumulated / spp
+        std::memcpy(rgb, r.framebuffer.data(), r.framebuffer.size() * sizeof(Vec3));
+    })
+}
+
 int hpt_host_save_ppm(const char* path, const float* rgb, int width, int height) {
     if (!path || !rgb || width <= 0 || height <= 0) return fail("bad argument");
     GUARD({

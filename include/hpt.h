@@ -35,7 +35,7 @@ typedef enum {
     HPT_ERR_INVALID_ARGUMENT = 1,
     HPT_ERR_HIP = 2,           /* a HIP runtime call failed; see hpt_last_error() */
     HPT_ERR_NO_SCENE = 3,      /* render/intersect before hpt_scene_upload */
-    HPT_ERR_OUT_OF_MEMORY = 4,
+    HPT_ERR_OUT_OF_MEMORY = 4, /* a device allocation found no room (scene upload, wavefront queues, ray staging) */
     HPT_ERR_TOO_LARGE = 5      /* fixed-capacity entry point: input exceeds its limit */
 } hpt_status;
 
@@ -165,7 +165,11 @@ int hpt_accum_clear(hpt_ctx* ctx, int64_t* accum_dev, void* stream);
  * (int64[3*width*height], row-major pixels, RGB interleaved; NULL = the
  * context's own buffer).  PathTrace(scene, iter) is sample_begin = iter,
  * sample_count = 1.  The sample index is part of the RNG key, so any split of
- * a sample range over calls, streams or GPUs yields the same sums.
+ * a sample range over calls, launches, contexts or GPUs yields the same sums.
+ * One render at a time per context: the work-unit counter and the wavefront
+ * queues belong to the context, so a call on another stream than the previous
+ * call's first makes that stream wait for the previous render (contexts are
+ * independent of each other; use one per stream for concurrent renders).
  *   mode:  HPT_MODE_SINGLE_KERNEL | HPT_MODE_STREAMED
  *   block: workgroup size (the CLI's <threads>), 1..1024
  *   max_depth: Scene::maxDepth, 0..16384
@@ -187,6 +191,12 @@ int hpt_resolve_dev(hpt_ctx* ctx, const int64_t* accum_dev, uint32_t spp_total, 
  *   shadow: NULL or uint8[n]; non-zero = any-hit query with tmax[n] = Ray::shadowDistance
  *   prim:   int32[n]  global primitive id, -1 = miss
  *   t:      double[n] Intersection::distance (1e30f on a miss)
+ * Closest-hit queries return the reference's (prim, t) exactly, ties included.  An any-hit query
+ * guarantees the reference's ANSWER -- occluded (prim >= 0) or not -- and a (prim, t) of some
+ * triangle that passes the reference's occlusion test; when several triangles pass it, scenes of
+ * more than 64 triangles may name another of them than BVHAccel::getIntersection's first in
+ * pre-order (their walk queues both children's leaves before descending).  The integrator only
+ * uses the answer (common/Scene.hpp:205-207).
  * Host-pointer form (copies in and out, synchronous) and device-pointer form
  * (asynchronous on `stream`). */
 int hpt_intersect_batch(hpt_ctx* ctx, size_t n, const float* o, const float* d, const uint8_t* shadow,

@@ -54,6 +54,11 @@ int hpt_host_bvh_dump(const hpt_host_scene* s, int mesh, int* count, float* boun
  * float[3*width*height] (Renderer::framebuffer).  stats may be NULL. */
 int hpt_host_render(const hpt_host_scene* s, int device, int spp, int max_depth, int num_threads, int mode, float* rgb,
                     hpt_stats* stats);
+/* The same picture through HipRenderer::PathTrace: PrepareRender, PathTrace(scene, iter) for iter in
+ * [0, spp) -- the per-sample loop of CudaRenderer::Render (gpu_path_tracer/CudaRenderer.cu:58-61) --
+ * then FinishRender, which downloads the framebuffer once. */
+int hpt_host_render_iterative(const hpt_host_scene* s, int device, int spp, int max_depth, int num_threads, int mode,
+                              float* rgb, hpt_stats* stats);
 /* Utility::SavePPM (common/Utility.cpp:4-22) */
 int hpt_host_save_ppm(const char* path, const float* rgb, int width, int height);
 /* Utility::SavePFM: linear float RGB as a portable float map (no counterpart in the reference) */

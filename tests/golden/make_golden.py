@@ -14,7 +14,8 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
-from orclib import MODELS, Material, Ref, fnv1a64, primary_rays, random_rays, shadow_rays  # noqa: E402
+from orclib import (MODELS, Material, Ref, bvh_hash, fnv1a64, fnv_bytes, primary_rays, random_rays, shadow_rays,  # noqa: E402
+                    shadow_rays_down)
 
 CAM = (278, 273, -800)
 
@@ -76,10 +77,77 @@ def glass(R):
     R.cornell(5)
 
 
+def write_obj(path, tris):
+    """A triangle soup (n, 3, 3) float32 as `v` / `f` records the reference's loader reads back
+    bit for bit (9 significant digits round-trip a float32 through std::stof)."""
+    with open(path, "w") as fh:
+        np.savetxt(fh, np.asarray(tris, np.float32).reshape(-1, 3).astype(np.float64), fmt="v %.9g %.9g %.9g")
+        np.savetxt(fh, np.arange(1, 3 * len(tris) + 1).reshape(-1, 3), fmt="f %d %d %d")
+
+
+def large_scenes(R):
+    """The scenes of the bunny and height-field configurations, which the reference has no
+    definition of: the triangle soups of cudapathtracer_amd/scenes.py written as OBJ files and
+    loaded by the reference's own MeshTriangle / Scene::Add / buildBVH.  Stored: the leaf order of
+    the large mesh, a hash over every BVH's bounds and links, (prim, t) on three seeded ray
+    batches and one small image of the reference renderer."""
+    import tempfile
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from cudapathtracer_amd import scenes
+    half_deg = np.float32(40 * 0.5)
+    half_rad = np.float32(np.float64(half_deg * np.float32(3.1415926535897932384626)) / 180.0)
+    scale = np.float32(np.tan(np.float64(half_rad)))
+    cases = [("bunny", scenes.bunny_in_cornell_parts()), ("heightfield64", scenes.heightfield_in_cornell_parts(64)),
+             ("heightfield708", scenes.heightfield_in_cornell_parts(708))]
+    for tag, parts in cases:
+        g = {}
+        small = tag != "heightfield708"   # the 1.0 M-triangle scene stores hashes and short batches only
+        w, h, depth, spp = 40, 32, 6, 2
+        with tempfile.TemporaryDirectory() as tmp:
+            R.begin(w, h, depth, CAM, 40.0)
+            for name, tris, mat in parts:
+                path = os.path.join(tmp, name + ".obj")
+                write_obj(path, tris)
+                R.add_obj(path, Material.make(**mat))
+            R.build()
+        info = R.info()
+        assert info["num_tris"] == sum(len(p[1]) for p in parts)
+        # the reference read back exactly the vertices that were written
+        for mesh, (_, tris, _) in enumerate(parts):
+            assert np.array_equal(R.mesh_triangles(mesh)[:, 0:3].view(np.int32), tris[:, 0].view(np.int32))
+        big = len(parts) - 1
+        order = R.bvh_dump(big)["payload"]
+        if small:
+            g["big_mesh_leaf_order"] = order
+        g["big_mesh_leaf_order_fnv"] = np.array([fnv_bytes(order.astype("<i4").tobytes())], np.uint64)
+        g["bvh_hashes"] = np.array([bvh_hash(R.bvh_dump(m)) for m in range(-1, info["num_meshes"])], np.uint64)
+        g["light_totals"] = np.array([info["sum_light_area"], info["sum_light_power"]], np.float32)
+        o, d = primary_rays(128, 128, CAM, scale)
+        p, t, agree, cnt = R.intersect(o, d)
+        assert agree.all()
+        g["grid128_prim"], g["grid128_t"] = p, t
+        g["grid128_counts_mean"] = cnt.mean(0)
+        nb = 16384 if small else 4096
+        o, d = random_rays(nb, 31)
+        p, t, agree, cnt = R.intersect(o, d)
+        assert agree.all()
+        g["rand_prim"], g["rand_t"] = p, t
+        g["rand_counts_mean"] = cnt.mean(0)
+        o, d, sh, tm = shadow_rays(nb, 32) if tag == "bunny" else shadow_rays_down(nb, 32)
+        p, t, agree, _ = R.intersect(o, d, sh, tm)
+        assert agree.all() and 0.02 < (p >= 0).mean() <= 1.0
+        g["shadow_prim"], g["shadow_t"] = p, t
+        g["img_r40x32_d6_spp2"] = R.render(spp)
+        np.savez_compressed(os.path.join(HERE, "scene_%s.npz" % tag), **g)
+    R.cornell(5)
+
+
 def main():
     R = Ref().cornell(5)
     if sys.argv[1:] == ["glass"]:
         return glass(R)
+    if sys.argv[1:] == ["scenes"]:
+        return large_scenes(R)
     info = R.info()
     assert info["num_tris"] == 32 and info["node_counter"] == 69
 
@@ -203,6 +271,7 @@ def main():
     sh["tone_out"] = np.array([R.lib.ref_tonemap(float(v)) for v in tv], np.int32)
     np.savez_compressed(os.path.join(HERE, "cornell_shading.npz"), **sh)
     glass(R)
+    large_scenes(R)
     for f in sorted(os.listdir(HERE)):
         print("%8d  %s" % (os.path.getsize(os.path.join(HERE, f)), f))
 

@@ -39,3 +39,15 @@ def shadow_rays(n, seed, lo=(0, 0, 0), hi=(556, 548.8, 559.2), light=((213, 548.
     d = (px * (np.float32(1) / ln)[:, None]).astype(np.float32)
     o = (p + d * np.float32(1e-5)).astype(np.float32)
     return o, d, np.ones(n, np.uint8), ln.astype(np.float64)
+
+
+def shadow_rays_down(n, seed):
+    """Any-hit queries from high points towards the floor: a height field faces up, so only rays
+    that come from above can be occluded by it."""
+    rs = np.random.RandomState(seed)
+    p = (rs.rand(n, 3) * [500, 300, 500] + [28, 200, 28]).astype(np.float32)
+    x = (rs.rand(n, 3) * [500, 0, 500] + [28, 0, 28]).astype(np.float32)
+    px = (x - p).astype(np.float32)
+    ln = np.sqrt((px[:, 0] * px[:, 0] + px[:, 1] * px[:, 1]) + px[:, 2] * px[:, 2], dtype=np.float32)
+    d = (px * (np.float32(1) / ln)[:, None]).astype(np.float32)
+    return (p + d * np.float32(1e-5)).astype(np.float32), d, np.ones(n, np.uint8), ln.astype(np.float64)

@@ -207,6 +207,10 @@ def test_cpp_hiprenderer_equals_c_abi(hp, oracle, gpu_ctx):
         rgb, st = sc.render_cpp(4, 5, 256, mode)
         assert st["paths"] == w * h * 4
         assert np.array_equal(rgb.view(np.int32), want.view(np.int32))
+        # PrepareRender, PathTrace(scene, iter) x spp, FinishRender: one download at the end
+        rgb, st = sc.render_cpp(4, 5, 256, mode, iterative=True)
+        assert st["paths"] == w * h * 4 and st["launches"] == (4 if mode == 1 else 8)
+        assert np.array_equal(rgb.view(np.int32), want.view(np.int32))
     r = hp.HipRenderer()
     r.spp = 4
     r.SetMode(hp.Streamed)
@@ -219,6 +223,39 @@ def test_cpp_hiprenderer_equals_c_abi(hp, oracle, gpu_ctx):
         r.PathTrace(sc, it)
     assert np.array_equal(r.framebuffer.view(np.int32), want.view(np.int32))
     r.FinishRender(sc)
+
+
+def test_many_renders_without_reading_stats_hold_few_events(hp, oracle, gpu_ctx):
+    """A PathTrace-style loop (one hpt_render per sample, statistics never read in between): the
+    timing events of completed renders are recycled, kernel time and launch count still add up."""
+    w, h, depth, n = 32, 32, 4, 300
+    sc = hp.Scene.CreateBuiltinScene(hp.Scene.CornellBox, depth, w, h)
+    gpu_ctx.upload(sc)
+    gpu_ctx.stats_reset()
+    gpu_ctx.accum_clear()
+    for it in range(n):
+        gpu_ctx.render(1 + it % 2, 256, depth, it, 1)
+    st = gpu_ctx.stats()
+    assert st["paths"] == w * h * n and st["launches"] == n // 2 + 2 * (n // 2) and st["kernel_ms"] > 0
+    want_acc, _ = oracle.cornell(w, h).render(RNG_PHILOX, TRIG_PORTABLE, depth, n, fixed=True)
+    assert np.array_equal(gpu_ctx.resolve(n).view(np.int32), oracle.resolve(want_acc, n).view(np.int32))
+
+
+def test_renders_on_two_streams_of_one_context_are_ordered(hp, oracle, gpu_ctx):
+    """The unit counter and the wavefront queues belong to the context; a render queued on another
+    stream waits for the one before it instead of racing with it."""
+    import torch
+    w, h, depth = 64, 64, 8
+    sc = hp.Scene.CreateBuiltinScene(hp.Scene.CornellBox, depth, w, h)
+    gpu_ctx.upload(sc)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    acc = torch.zeros(3 * w * h, dtype=torch.int64, device="cuda:0")
+    torch.cuda.synchronize()
+    for k in range(6):
+        gpu_ctx.render(1 + k % 2, 256, depth, 4 * k, 4, accum=acc, stream=(s1 if k % 2 == 0 else s2))
+    torch.cuda.synchronize()
+    want_acc, _ = oracle.cornell(w, h).render(RNG_PHILOX, TRIG_PORTABLE, depth, 24, fixed=True)
+    assert np.array_equal(acc.cpu().numpy().reshape(-1, 3), want_acc)
 
 
 def test_wavefront_small_capacity_batches(hp, oracle, gpu_ctx):

@@ -357,3 +357,22 @@ def test_save_pfm_round_trip(hp, tmp_path):
 
 def test_cli_is_built():
     assert os.access(os.path.join(ROOT, "build", "gpu_path_tracer"), os.X_OK)
+
+
+@pytest.mark.parametrize("tag", ["bunny", "heightfield64", "heightfield708"])
+def test_host_bvh_equals_the_reference_on_large_scenes(hp, tag):
+    """The product's own BVH builder (host/BVH.cpp) against what the COMPILED REFERENCE built from
+    the same triangle soups (tests/golden/scene_*.npz): leaf order of the large mesh, and bounds,
+    miss links and payloads of the top-level BVH and of every mesh BVH."""
+    from cudapathtracer_amd import scenes
+    from orclib import bvh_hash, fnv_bytes
+    g = np.load(os.path.join(G, "scene_%s.npz" % tag))
+    parts = scenes.bunny_in_cornell_parts() if tag == "bunny" else scenes.heightfield_in_cornell_parts(int(tag[11:]))
+    sc = scenes._assemble(parts, 40, 32, 6)
+    order = sc.bvh_dump(len(parts) - 1)["payload"]
+    if "big_mesh_leaf_order" in g:
+        assert np.array_equal(order, g["big_mesh_leaf_order"])
+    assert fnv_bytes(order.astype("<i4").tobytes()) == int(g["big_mesh_leaf_order_fnv"][0])
+    assert [bvh_hash(sc.bvh_dump(m)) for m in range(-1, len(parts))] == [int(v) for v in g["bvh_hashes"]]
+    f = sc.flat_arrays()
+    assert np.array_equal(bits(np.array([f["sum_light_area"], f["sum_light_power"]], np.float32)), bits(g["light_totals"]))
