@@ -108,6 +108,7 @@ def _declare(L, H):
     L.hpt_octant_copies.argtypes = [C.POINTER(hpt_scene_desc), C.c_int, vp, vp]
     L.hpt_accum_clear.argtypes = [vp, vp, vp]
     L.hpt_render.argtypes = [vp, i32, i32, i32, u32, u32, vp, vp]
+    L.hpt_render_static.argtypes = [vp, i32, i32, i32, u32, u32, vp, vp]
     L.hpt_resolve.argtypes = [vp, vp, u32, vp, vp]
     L.hpt_resolve_dev.argtypes = [vp, vp, u32, vp, vp]
     L.hpt_intersect_batch.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, vp, vp]
@@ -314,6 +315,11 @@ class Context:
     def render(self, mode, block, max_depth, sample_begin, sample_count, accum=None, stream=None):
         _ck(self._L.hpt_render(self._h, int(mode), int(block), int(max_depth), int(sample_begin), int(sample_count),
                                _ptr(accum), _stream(stream)))
+
+    def render_static(self, mode, block, max_depth, sample_begin, sample_count, accum=None, stream=None):
+        """hpt_render_static: the render that allocates nothing (at most 2^18 camera paths per call)."""
+        _ck(self._L.hpt_render_static(self._h, int(mode), int(block), int(max_depth), int(sample_begin),
+                                      int(sample_count), _ptr(accum), _stream(stream)))
 
     def resolve(self, spp_total, accum=None, stream=None):
         rgb = np.zeros((self.width * self.height, 3), np.float32)

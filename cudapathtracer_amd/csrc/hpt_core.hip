@@ -25,11 +25,16 @@
 #include <cstring>
 #include <string>
 #include <functional>
+#include <mutex>
 #include <vector>
 
 #include "hpt_device.h"
 
 using namespace hpt;
+
+// In host code this name is only a handle for hipGetSymbolAddress: the array's device address
+// (per GPU) is looked up once per device in scratch_of() and only that pointer is passed on.
+static __device__ __align__(256) unsigned char scratch[(1ull << 18) * 128ull + 4096ull * 4ull + 256ull];
 
 namespace {
 
@@ -41,6 +46,37 @@ constexpr int kStatClosest = 0, kStatShadow = 1, kStatPaths = 2, kNumStats = 4;
 
 thread_local std::string g_last_error;
 
+// Scratch of hpt_render_static, the entry point that allocates nothing: one work-unit counter,
+// the per-segment live counters and the two wavefront path queues of a render of at most
+// kStaticPaths camera paths.  Every GPU the library runs on holds its own copy of the array until
+// the process ends; all calls on a GPU share it.
+constexpr uint64_t kStaticPaths = 1ull << 18;      // 512 x 512 pixels x 1 sample
+constexpr uint32_t kStaticSegments = 4096;         // live counters (one per resident workgroup)
+constexpr size_t kScratchCounterBytes = 256;
+constexpr size_t kScratchLiveBytes = kStaticSegments * sizeof(uint32_t);
+constexpr size_t kScratchQueueBytes = 8ull * kStaticPaths * 16ull;  // 8 planes of float4: 32 MiB
+constexpr size_t kScratchBytes = kScratchCounterBytes + kScratchLiveBytes + kScratchQueueBytes;
+constexpr int kMaxDevices = 64;
+
+static_assert(sizeof(scratch) == kScratchBytes, "scratch array and its layout constants disagree");
+
+int fail(int code, const char* fmt, ...);
+
+// device address of `scratch` on `device` (which must be current); looked up once per device
+std::mutex g_scratch_mutex;
+unsigned char* g_scratch_ptr[kMaxDevices] = {};
+int scratch_of(int device, unsigned char** out) {
+    if (device < 0 || device >= kMaxDevices) return fail(HPT_ERR_INVALID_ARGUMENT, "device %d: the static scratch serves devices 0..%d", device, kMaxDevices - 1);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) return fail(HPT_ERR_HIP, "hipGetSymbolAddress(scratch) on device %d failed: %s", device, hipGetErrorString(e));
+        g_scratch_ptr[device] = static_cast<unsigned char*>(p);
+    }
+    *out = g_scratch_ptr[device];
+    return HPT_OK;
+}
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -519,6 +555,7 @@ struct hpt_ctx {
     // timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;
     hipStream_t last_stream = nullptr;  // stream of the most recent hpt_render
+    unsigned char* scratch_dev = nullptr;  // this GPU's copy of the static scratch (hpt_render_static)
     std::vector<hipEvent_t> free_events;
     double kernel_ms = 0.0;
     uint32_t launches = 0;
@@ -1121,6 +1158,12 @@ int hpt_context_create(int device, hpt_ctx** out) {
         delete ctx;
         return fail(HPT_ERR_HIP, "stats buffer: %s", hipGetErrorString(e));
     }
+    if (int rc = scratch_of(device, &ctx->scratch_dev)) {
+        (void)hipFree(ctx->d_stats);
+        (void)hipFree(ctx->d_unit_counter);
+        delete ctx;
+        return rc;
+    }
 #ifdef HPT_PROFILE
     (void)hipMalloc((void**)&ctx->d_prof, 3 * kProfSections * sizeof(unsigned long long));
     (void)hipMemset(ctx->d_prof, 0, 3 * kProfSections * sizeof(unsigned long long));
@@ -1440,6 +1483,34 @@ int hpt_render(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sample
         return rc != HPT_OK ? rc : fail(HPT_ERR_HIP, "hipEventRecord failed: %s", hipGetErrorString(e));
     }
     ctx->pending_events.emplace_back(ev0, ev1);
+    ctx->launches += launches;
+    return HPT_OK;
+}
+
+int hpt_render_static(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sample_begin, uint32_t sample_count,
+                      int64_t* accum_dev, void* stream_) {
+    if (int rc = check_render_args(ctx, mode, block, max_depth, sample_begin, sample_count)) return rc;
+    if (int rc = set_device(ctx)) return rc;
+    if (sample_count == 0 || max_depth == 0) return HPT_OK;
+    const DevScene& S = ctx->S;
+    const uint64_t lanes = (uint64_t)(((uint32_t)S.width + 7u) >> 3) * (((uint32_t)S.height + 7u) >> 3) * 64ull;
+    if (lanes * (uint64_t)sample_count > kStaticPaths)
+        return fail(HPT_ERR_TOO_LARGE, "hpt_render_static traces at most %llu camera paths per call (8x8-pixel tiles x 64 x samples); this call asks for %llu",
+                    (unsigned long long)kStaticPaths, (unsigned long long)(lanes * sample_count));
+    unsigned char* base = ctx->scratch_dev;  // the array's address on this GPU, never the symbol's name
+    RenderBuffers buf{};
+    buf.unit_counter = reinterpret_cast<uint32_t*>(base);
+    buf.live = reinterpret_cast<uint32_t*>(base + kScratchCounterBytes);
+    buf.live_slots = kStaticSegments;
+    buf.wf_paths = kStaticPaths;
+    for (int i = 0; i < 8; ++i) buf.wf[i] = reinterpret_cast<float4*>(base + kScratchCounterBytes + kScratchLiveBytes) + (size_t)i * kStaticPaths;
+    // Nothing in the scratch has to start at zero except the unit counter, which render_launch
+    // clears on the stream before each single-kernel launch; the generate kernel writes every
+    // live counter and every path record the bounce kernel reads.
+    uint32_t launches = 0;
+    if (int rc = render_launch(ctx, mode, block, max_depth, sample_begin, sample_count, accum_dev ? accum_dev : ctx->d_accum,
+                               (hipStream_t)stream_, &buf, &launches))
+        return rc;
     ctx->launches += launches;
     return HPT_OK;
 }

@@ -177,6 +177,22 @@ int hpt_accum_clear(hpt_ctx* ctx, int64_t* accum_dev, void* stream);
 int hpt_render(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sample_begin, uint32_t sample_count,
                int64_t* accum_dev, void* stream);
 
+/* hpt_render for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.
+ * Same arguments, same kernels and bit-identical sums as hpt_render, but every buffer beyond the
+ * caller's accumulators -- the work-unit counter, the per-segment live counters and the two
+ * wavefront path queues -- lies in a 32 MiB + 17 KiB array that is part of the library's code
+ * object (each GPU the library runs on holds its copy until the process ends), and the call takes
+ * no timing events: it calls no hipMalloc, hipFree or hipEventCreate.  hpt_stats.kernel_ms does not
+ * include these renders; the ray counters and `launches` do.
+ *   Limit: at most 2^18 = 262 144 camera paths per call, counted as
+ *   ceil(width/8) * ceil(height/8) * 64 * sample_count (512 x 512 pixels x 1 sample, 64 x 64 x 64
+ *   samples, ...); beyond that the call returns HPT_ERR_TOO_LARGE and does nothing.
+ *   All calls on one GPU share that GPU's array, whatever their context or stream: calls that
+ *   overlap on one GPU race.  Queue them on one stream, or order them with events. */
+int hpt_render_static(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sample_begin, uint32_t sample_count,
+                      int64_t* accum_dev, void* stream);
+
 /* Replaces the cudaMemcpy D2H of CudaRenderer::Render (gpu_path_tracer/CudaRenderer.cu:63-67):
  * converts the accumulators to float RGB divided by spp_total (what
  * Renderer::framebuffer holds in the reference) and copies them to host
