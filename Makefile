@@ -3,6 +3,8 @@
 #   make hpt      cudapathtracer_amd/libhpt.so        HIP kernels + C ABI (include/hpt.h)
 #   make host     cudapathtracer_amd/libhpt_host.so   C++ host API (Scene/BVHAccel/Material/HipRenderer)
 #                 build/gpu_path_tracer               the CLI
+#   make count    cudapathtracer_amd/libhpt_count.so  diagnostic build of libhpt.so that counts the box and
+#                                                      triangle tests the kernels execute (tools/count_tests.py)
 #   make oracle   oracle/liboracle.so                 CPU restatement (test infrastructure)
 #   make ref      oracle/_ref/libref.so               the compiled reference (needs /root/reference)
 #
@@ -29,12 +31,16 @@ HOST_SRCS := $(HOST)/BVH.cpp $(HOST)/Scene.cpp $(HOST)/Triangle.cpp $(HOST)/Util
              $(HOST)/HipRenderer.cpp $(HOST)/host_capi.cpp
 HOST_HDRS := $(wildcard $(HOST)/*.hpp) include/hpt.h include/hpt_host.h
 
-.PHONY: all hpt host oracle ref clean
+.PHONY: all hpt host oracle ref clean count
 all: hpt host oracle
 
 hpt: $(PKG)/libhpt.so
 $(PKG)/libhpt.so: $(CSRC)/hpt_core.hip $(CSRC)/hpt_device.h include/hpt.h Makefile
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/hpt_core.hip
+
+count: $(PKG)/libhpt_count.so
+$(PKG)/libhpt_count.so: $(CSRC)/hpt_core.hip $(CSRC)/hpt_device.h include/hpt.h Makefile
+	$(HIPCC) $(HIPFLAGS) -DHPT_COUNT_TESTS -shared -o $@ $(CSRC)/hpt_core.hip
 
 host: $(PKG)/libhpt_host.so build/gpu_path_tracer
 $(PKG)/libhpt_host.so: $(HOST_SRCS) $(HOST_HDRS) $(PKG)/libhpt.so
@@ -51,5 +57,5 @@ ref:
 	$(MAKE) -C oracle ref
 
 clean:
-	rm -rf $(PKG)/libhpt.so $(PKG)/libhpt_host.so build
+	rm -rf $(PKG)/libhpt.so $(PKG)/libhpt_count.so $(PKG)/libhpt_host.so build
 	$(MAKE) -C oracle clean

@@ -24,35 +24,87 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# dense FP32 vector peak of MI355X (157.3 TFLOP/s counts an FMA as 2 flops)
+# dense FP32 vector peak of MI355X (157.3 TFLOP/s counts an FMA as 2 flops); HBM3E peak; aggregate
+# L2 bandwidth of the eight XCDs (MI355X_MICROARCH.md: 8 TB/s and 34.5 TB/s)
 PEAK_FP32_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0
+L2_PEAK_GBS = 34500.0
+L2_BYTES_PER_XCD = 4 << 20
 # algorithmic work per unit: one box test = 24 flops (6 sub, 6 mul, ~12 compare/select) and one
 # node record, priced at 64 B like a triangle record; one triangle test = 70 flops / 64 B; one
 # shaded bounce = 350 flops.  Tests are counted as the reference traversal defines them, by the
-# CPU restatement, not by what the GPU kernel happens to execute.
+# CPU restatement on a bounded sample of the benchmarked scene, not by what the GPU kernel
+# happens to execute (that is reported beside it, from profiles/executed_tests.json).
 FLOPS_BOX, FLOPS_TRI, FLOPS_BOUNCE = 24.0, 70.0, 350.0
 BYTES_BOX, BYTES_TRI = 64.0, 64.0
 
 
-def cpu_baseline(width, height, depth, spp, threads):
-    """The CPU restatement of the reference renderer (its own RNG stream and
-    libm), timed on the host cores on a bounded sample of the same workload.
-    Also returns the per-ray box/triangle test counts the roofline is priced with."""
+def scene_parts(name):
+    """(name, triangles, material) lists of the non-Cornell bench scenes (pure numpy)."""
+    from cudapathtracer_amd import scenes
+    if name == "bunny":
+        return scenes.bunny_in_cornell_parts()
+    if name == "glass":
+        return scenes.glass_cornell_parts()
+    if name.startswith("heightfield:"):
+        return scenes.heightfield_in_cornell_parts(int(name.split(":")[1]))
+    raise SystemExit("unknown --scene " + name)
+
+
+def host_cpu():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return model, os.cpu_count() or 1
+
+
+def cpu_baseline(scene, width, height, depth, spp):
+    """The CPU restatement of the reference renderer (its own RNG stream and libm), timed on the
+    host cores on a bounded sample of the same workload: the benchmarked scene at the benchmark's
+    depth, full resolution for the Cornell box, 512 x 512 for the large scenes (whose CPU rays are
+    several times slower).  Also returns the per-ray box/triangle test counts of the REFERENCE
+    traversal on that scene, which the roofline is priced with."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from orclib import RNG_MT, TRIG_LIBM, Oracle
-    osc = Oracle().cornell(width, height)
+    from orclib import RNG_MT, TRIG_LIBM, Material, Oracle
+    model, ncpu = host_cpu()
+    # the GPU box gives a job 16 of the machine's CPUs (OMP_NUM_THREADS is set to that share there)
+    threads = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or ncpu, ncpu))
+    if scene == "cornell":
+        osc = Oracle().cornell(width, height)
+    else:
+        from cudapathtracer_amd import scenes
+        width = height = 512
+        osc = Oracle().scene(width, height, scenes.CORNELL_CAM, 40.0)
+        for _, tris, mat in scene_parts(scene):
+            osc.add_triangles(tris, Material.make(**mat))
+        osc.build()
     t0 = time.perf_counter()
     _, st = osc.render(RNG_MT, TRIG_LIBM, depth, spp, threads=threads)
     dt = time.perf_counter() - t0
     rays = st["closest_queries"] + st["shadow_queries"]
     return {
         "value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-        "sample": "Cornell %dx%d depth %d, %d spp (%.1f M rays) in %.2f s; %.3f spp/s" % (
-            width, height, depth, spp, rays / 1e6, dt, spp / dt),
+        "cpu_model": model, "host_cpus": ncpu,
+        "threads_note": "OpenMP threads = OMP_NUM_THREADS (the job's CPU share on the GPU box) capped at the host's CPU count",
+        "sample": "%s %dx%d depth %d, %d spp (%.1f M rays) in %.2f s; %.3f spp/s at this resolution" % (
+            scene, width, height, depth, spp, rays / 1e6, dt, spp / dt),
         "spp_per_sec": spp / dt,
+        "relation_to_reference": "the restatement renders the reference's image bit for bit and runs 1.09-1.15x as fast as the "
+                                 "compiled reference on the same cores (BASELINE.md)",
     }, {"box_per_ray": st["box_tests"] / rays, "tri_per_ray": st["tri_tests"] / rays,
         "rays_per_path": rays / st["paths"]}
+
+
+def load_json(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return {}
 
 
 def main():
@@ -123,13 +175,7 @@ def main():
         scene = hp.Scene.CreateBuiltinScene(hp.Scene.CornellBox, depth, W, H)
     else:
         from cudapathtracer_amd import scenes
-        args.no_cpu_baseline = True
-        if args.scene == "bunny":
-            scene = scenes.bunny_in_cornell(W, H, depth)
-        elif args.scene.startswith("heightfield:"):
-            scene = scenes.heightfield_in_cornell(int(args.scene.split(":")[1]), W, H, depth)
-        else:
-            sys.exit("unknown --scene " + args.scene)
+        scene = scenes._assemble(scene_parts(args.scene), W, H, depth)
     ctx = hp.Context(dev_index)
     if args.traversal == "culled":
         ctx.set_traversal(1)
@@ -185,31 +231,64 @@ def main():
 
         cpu, per_ray = None, None
         if world == 1 and not args.no_cpu_baseline and args.cpu_spp > 0:
-            threads = max(1, min(16, os.cpu_count() or 1))
-            cpu, per_ray = cpu_baseline(W, H, depth, args.cpu_spp, threads)
-        if per_ray is None:
-            # reference traversal cost of this workload measured once with the CPU
-            # restatement (Cornell 1024x1024, depth 20)
-            per_ray = {"box_per_ray": 29.33, "tri_per_ray": 5.62, "rays_per_path": 11.64}
+            cpu, per_ray = cpu_baseline(args.scene, W, H, depth, args.cpu_spp)
 
         launches = max(1, st["launches"])
-        kernel_ms = st["kernel_ms"] / launches            # rank 0's average launch, HIP events on its stream
+        if args.mode == 2:
+            launches //= 2                                # a streamed batch = generate + bounce loop: priced as one unit
+        kernel_ms = st["kernel_ms"] / max(1, launches)    # rank 0's average launch, HIP events on its stream
         rays_per_launch = rays / launches
         closest_per_launch = st["closest_queries"] / launches
-        flops = rays_per_launch * (FLOPS_BOX * per_ray["box_per_ray"] + FLOPS_TRI * per_ray["tri_per_ray"]) \
-            + closest_per_launch * FLOPS_BOUNCE
-        byts = rays_per_launch * (BYTES_BOX * per_ray["box_per_ray"] + BYTES_TRI * per_ray["tri_per_ray"])
-        achieved_tflops = flops / (kernel_ms * 1e-3) / 1e12
-        traffic = active_lanes = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                key = "mode%d_%dx%d_d%d_spp%d" % (args.mode, W, H, depth, spp_step)
-                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
-                active_lanes = tj.get(key, {}).get("valu_active_lane_fraction")
-            except Exception:
-                traffic = None
+        # where the traversal's records live decides the bound: LDS (staged per workgroup) -> VALU issue;
+        # read through L1/L2 -> L2 bandwidth while the records fit one XCD's L2, HBM beyond
+        variant = st["variant"]
+        desc = scene.describe()
+        record_bytes = 64 * (desc.num_tris + desc.num_nodes // 2)    # triangle records + two-child records
+        bound = "valu" if variant in (1, 2, 3, 6) else ("l2" if record_bytes <= L2_BYTES_PER_XCD else "hbm")
+        key = "%s_mode%d_%dx%d_d%d_spp%d" % (args.scene, args.mode, W, H, depth, spp_step) + ("_culled" if args.traversal == "culled" else "")
+        pm = load_json("hbm_traffic.json").get(key, {})
+        ex = load_json("executed_tests.json").get("%s_%dx%d_d%d_mode%d" % (args.scene, W, H, depth, args.mode)
+                                                  + ("_culled" if args.traversal == "culled" else ""), {})
+        roof = {"bound": bound, "achieved": None, "peak": None, "unit": None, "frac": None,
+                "traffic": pm.get("hbm_bytes_per_launch"),
+                "kernel": "k_render_mega" if args.mode == 1 else "k_wf_bounces (+ k_wf_generate)",
+                "kernel_ms": kernel_ms, "launches": launches, "traversal_variant": variant,
+                "scene_record_bytes": record_bytes,
+                "valu_active_lane_fraction": pm.get("valu_active_lane_fraction"),   # PMC, same source file as `traffic`
+                "l2_hit_rate": pm.get("l2_hit_rate"), "counter_source": pm.get("source")}
+        if per_ray is not None:
+            flops = rays_per_launch * (FLOPS_BOX * per_ray["box_per_ray"] + FLOPS_TRI * per_ray["tri_per_ray"]) \
+                + closest_per_launch * FLOPS_BOUNCE
+            byts = rays_per_launch * (BYTES_BOX * per_ray["box_per_ray"] + BYTES_TRI * per_ray["tri_per_ray"])
+            tflops = flops / (kernel_ms * 1e-3) / 1e12
+            gbps = byts / (kernel_ms * 1e-3) / 1e9
+            if bound == "valu":
+                roof.update(achieved=tflops, peak=PEAK_FP32_TFLOPS, unit="TFLOP/s", frac=tflops / PEAK_FP32_TFLOPS)
+            else:
+                peak = L2_PEAK_GBS if bound == "l2" else HBM_PEAK_GBS
+                roof.update(achieved=gbps, peak=peak, unit="GB/s", frac=gbps / peak)
+            roof.update({
+                "algorithmic_flops_per_launch": flops, "algorithmic_TFLOPs": tflops,
+                "algorithmic_bytes_per_launch": byts, "algorithmic_record_GBps": gbps,
+                "box_tests_per_ray": per_ray["box_per_ray"], "tri_tests_per_ray": per_ray["tri_per_ray"],
+                "note": "algorithmic work = box/triangle tests as the REFERENCE traversal defines them on this scene (counted by the "
+                        "CPU oracle on the cpu_baseline sample): 24 flops and one 64-byte record per box test, 70 flops and one record "
+                        "per triangle test, 350 flops per shaded bounce. " +
+                        ("The records are staged in LDS per workgroup, so the record byte rate is an LDS rate, not HBM traffic."
+                         if bound == "valu" else
+                         "The records are read through L1/L2" + ("; the scene fits one XCD's L2, HBM traffic is nil." if bound == "l2" else
+                                                                 "; the scene is larger than the L2s: `traffic` is what crossed the fabric.")),
+            })
+            if ex:
+                eflops = rays_per_launch * (FLOPS_BOX * ex["executed_box_tests_per_ray"] + FLOPS_TRI * ex["executed_tri_tests_per_ray"]) \
+                    + closest_per_launch * FLOPS_BOUNCE
+                ebytes = rays_per_launch * (0.5 * BYTES_BOX * ex["executed_box_tests_per_ray"] + BYTES_TRI * ex["executed_tri_tests_per_ray"])
+                roof["executed"] = {
+                    "box_tests_per_ray": ex["executed_box_tests_per_ray"], "tri_tests_per_ray": ex["executed_tri_tests_per_ray"],
+                    "TFLOPs": eflops / (kernel_ms * 1e-3) / 1e12, "frac_of_fp32_peak": eflops / (kernel_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
+                    "record_GBps": ebytes / (kernel_ms * 1e-3) / 1e9,
+                    "note": "tests the kernel executes (diagnostic counting build, profiles/executed_tests.json); a fetched record "
+                            "holds two boxes (32 bytes per box test)"}
         out = {
             "metric": "Mrays/sec + spp/sec (whole node), Cornell 1k^2 depth 20",
             "value": total_rays / elapsed / 1e6,
@@ -219,29 +298,15 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (+f64 in the triangle test, int64 accumulators)",
-            "data": "synthetic: built-in Cornell box (models/cornellbox), Philox-keyed samples",
+            "data": "synthetic: %s, Philox-keyed samples" % ("built-in Cornell box (models/cornellbox)" if args.scene == "cornell" else args.scene),
             "config": {"workload": "%s %dx%d, depth %d, mode %d (%s), block %d, %d spp per step per GPU; "
-                                   "%d spp total of the 4096-spp config" % (
+                                   "%d spp in the timed region" % (
                                        "Cornell box" if args.scene == "cornell" else args.scene, W, H, depth, args.mode, "single kernel" if args.mode == 1 else "streamed", args.block,
                                        spp_step, total_spp),
                        "rays_per_path": total_rays / total_paths,
+                       "traversal": args.traversal,
                        "parallelism": "spp-sharded x%d, one RCCL reduce" % world if world > 1 else "1 GPU"},
-            "roofline": {
-                "bound": "valu", "achieved": achieved_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved_tflops / PEAK_FP32_TFLOPS, "traffic": traffic,
-                "kernel": "k_render_mega" if args.mode == 1 else "k_wf_bounces",
-                "valu_active_lane_fraction": active_lanes,   # PMC, same source file as `traffic`
-                "kernel_ms": kernel_ms, "launches": launches,
-                "algorithmic_flops_per_launch": flops,
-                "algorithmic_bytes_per_launch": byts,
-                "algorithmic_GBps": byts / (kernel_ms * 1e-3) / 1e9,
-                "hbm_peak_GBps": HBM_PEAK_GBS,
-                "note": ("scene is LDS-resident (20 KiB per workgroup): the kernel is VALU-issue / divergence bound, not HBM bound; "
-                         if args.scene == "cornell" else "scene records are read through L1/L2; ") +
-                        "flops/ray = 24*box_tests + 70*tri_tests (+350 per shaded bounce), tests as the reference traversal "
-                        "defines them, counted by the CPU oracle",
-                "box_tests_per_ray": per_ray["box_per_ray"], "tri_tests_per_ray": per_ray["tri_per_ray"],
-            },
+            "roofline": roof,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))

@@ -51,12 +51,13 @@ class hpt_scene_desc(C.Structure):
 
 class hpt_stats(C.Structure):
     _fields_ = [("closest_queries", C.c_uint64), ("shadow_queries", C.c_uint64), ("paths", C.c_uint64),
-                ("kernel_ms", C.c_double), ("launches", C.c_uint32), ("variant", C.c_uint32)]
+                ("kernel_ms", C.c_double), ("launches", C.c_uint32), ("variant", C.c_uint32),
+                ("box_tests", C.c_uint64), ("tri_tests", C.c_uint64)]
 
     def as_dict(self):
         return dict(closest_queries=int(self.closest_queries), shadow_queries=int(self.shadow_queries),
                     paths=int(self.paths), kernel_ms=float(self.kernel_ms), launches=int(self.launches),
-                    variant=int(self.variant))
+                    variant=int(self.variant), box_tests=int(self.box_tests), tri_tests=int(self.tri_tests))
 
 
 def Material(type=0, emission=(0.0, 0.0, 0.0), albedo=(0.9, 0.9, 0.9), metallic=0.0, roughness=1.0, ior=0.0):

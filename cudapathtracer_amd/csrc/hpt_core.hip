@@ -42,7 +42,7 @@ constexpr uint32_t kLdsLimit = 32u * 1024u;
 constexpr uint32_t kLdsLimitTiny = 44u * 1024u;  // nine node copies of a 64-triangle scene (127 nodes) + its triangles
 constexpr uint32_t kMaxLdsPerBlock = 160u * 1024u;  // LDS of a gfx950 compute unit; one workgroup may use all of it
 constexpr uint32_t kMaxStackDepth = 40;  // per-lane stack entries (4 B each in LDS); median-split trees need ~log2(triangles)
-constexpr int kStatClosest = 0, kStatShadow = 1, kStatPaths = 2, kNumStats = 4;
+constexpr int kStatClosest = 0, kStatShadow = 1, kStatPaths = 2, kStatBox = 3, kStatTri = 4, kNumStats = 6;
 
 thread_local std::string g_last_error;
 
@@ -131,6 +131,22 @@ __device__ __forceinline__ void stat_add(unsigned long long* slot, uint32_t v) {
     if ((threadIdx.x & 63u) == 0u && sum) atomicAdd(slot, sum);
 }
 
+#ifdef HPT_COUNT_TESTS
+__device__ __forceinline__ void count_flush(unsigned long long* stats, TestCount& c) {
+    // low words through the wave sum, the (rare) high words lane by lane
+    stat_add(stats + kStatBox, (uint32_t)c.box);
+    stat_add(stats + kStatTri, (uint32_t)c.tri);
+    if (c.box >> 32) atomicAdd(stats + kStatBox, (c.box >> 32) << 32);
+    if (c.tri >> 32) atomicAdd(stats + kStatTri, (c.tri >> 32) << 32);
+    c.box = c.tri = 0;
+}
+#define COUNT_DECL TestCount tcount{0ull, 0ull}
+#define COUNT_FLUSH(stats) count_flush(stats, tcount)
+#else
+#define COUNT_DECL
+#define COUNT_FLUSH(stats)
+#endif
+
 template <int kScene>
 __global__ void k_intersect_batch(DevScene S, size_t n, const float* __restrict__ o, const float* __restrict__ d,
                                   const uint8_t* __restrict__ shadow, const double* __restrict__ tmax,
@@ -144,13 +160,14 @@ __global__ void k_intersect_batch(DevScene S, size_t n, const float* __restrict_
     ProfAcc prof;
     prof.w = prof_dummy;
 #endif
+    COUNT_DECL;
     for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) {
         const f3 ro = mk(o[3 * r], o[3 * r + 1], o[3 * r + 2]);
         const f3 rd = mk(d[3 * r], d[3 * r + 1], d[3 * r + 2]);
         int tri;
         double t;
-        if (shadow && shadow[r]) trace<kScene, true>(S, lds, tq, ro, rd, tmax[r], tri, t PROF_PASS);
-        else trace<kScene, false>(S, lds, tq, ro, rd, 0.0, tri, t PROF_PASS);
+        if (shadow && shadow[r]) trace<kScene, true>(S, lds, tq, ro, rd, tmax[r], tri, t PROF_PASS COUNT_PASS);
+        else trace<kScene, false>(S, lds, tq, ro, rd, 0.0, tri, t PROF_PASS COUNT_PASS);
         prim[r] = tri < 0 ? -1 : __float_as_int(S.tris[4 * tri + 2].w);
         t_out[r] = t;
     }
@@ -223,6 +240,7 @@ k_render_mega(DevScene S, int max_depth, uint32_t s_begin_all, uint32_t s_count_
     // (s_chunk + 2) * max_depth <= 65535 loop iterations between two openings, checked by the host)
     uint32_t n_rays = 0, n_paths_wave = 0;
     uint32_t slot = 0, lane_gen = 0;
+    COUNT_DECL;
     bool alive = false;
     Path p;
 #ifdef HPT_PROFILE
@@ -302,8 +320,8 @@ k_render_mega(DevScene S, int max_depth, uint32_t s_begin_all, uint32_t s_count_
             int tri;
             double t;
             ++n_rays;
-            trace<kScene, false>(S, lds, tq, p.o, p.d, 0.0, tri, t PROF_PASS);
-            alive = shade_bounce<kScene, kGlass, 0x10000u>(S, lds, tq, p, tri, t, n_rays PROF_PASS) && p.depth < max_depth;
+            trace<kScene, false>(S, lds, tq, p.o, p.d, 0.0, tri, t PROF_PASS COUNT_PASS);
+            alive = shade_bounce<kScene, kGlass, 0x10000u>(S, lds, tq, p, tri, t, n_rays PROF_PASS COUNT_PASS) && p.depth < max_depth;
             if (!alive) {
                 unsigned long long* acc = tile_acc + lane_gen * 192u + 3u * slot;
                 atomicAdd(acc + 0u, (unsigned long long)radiance_to_fixed(p.rad.x));
@@ -322,6 +340,7 @@ k_render_mega(DevScene S, int max_depth, uint32_t s_begin_all, uint32_t s_count_
     stat_add(stats + kStatClosest, n_rays & 0xFFFFu);
     stat_add(stats + kStatShadow, n_rays >> 16);
     stat_add(stats + kStatPaths, lane == 0 ? n_paths_wave : 0u);
+    COUNT_FLUSH(stats);
 }
 
 // ---- wavefront: 64-byte path records as four float4 planes -----------------
@@ -439,6 +458,7 @@ k_wf_bounces(DevScene S, int max_depth, uint32_t seg, WfQueue q0, WfQueue q1, co
     const size_t seg_base = (size_t)blockIdx.x * seg;
     const TriQueue tq = make_tri_queue<kScene>(reinterpret_cast<uint32_t*>(lds + S.lds_float4s));
     uint32_t n_closest = 0, n_shadow = 0;
+    COUNT_DECL;
 #ifdef HPT_PROFILE
     __shared__ unsigned long long prof_dummy[3 * kProfSections];
     ProfAcc prof;
@@ -469,8 +489,8 @@ k_wf_bounces(DevScene S, int max_depth, uint32_t seg, WfQueue q0, WfQueue q1, co
                     int tri;
                     double t;
                     ++n_closest;
-                    trace<kScene, false>(S, lds, tq, p.o, p.d, 0.0, tri, t PROF_PASS);
-                    keep = shade_bounce<kScene, kGlass>(S, lds, tq, p, tri, t, n_shadow PROF_PASS) && p.depth < max_depth;
+                    trace<kScene, false>(S, lds, tq, p.o, p.d, 0.0, tri, t PROF_PASS COUNT_PASS);
+                    keep = shade_bounce<kScene, kGlass>(S, lds, tq, p, tri, t, n_shadow PROF_PASS COUNT_PASS) && p.depth < max_depth;
                     if (!keep) accumulate_pixel(accum, p.pixel, p.rad);
                 }
             }
@@ -489,6 +509,7 @@ k_wf_bounces(DevScene S, int max_depth, uint32_t seg, WfQueue q0, WfQueue q1, co
     }
     stat_add(stats + kStatClosest, n_closest);
     stat_add(stats + kStatShadow, n_shadow);
+    COUNT_FLUSH(stats);
 }
 
 __global__ void k_resolve(const int64_t* __restrict__ accum, size_t n, double denom, float* __restrict__ rgb) {
@@ -1613,6 +1634,8 @@ int hpt_stats_get(hpt_ctx* ctx, hpt_stats* out) {
     out->closest_queries = h[kStatClosest];
     out->shadow_queries = h[kStatShadow];
     out->paths = h[kStatPaths];
+    out->box_tests = h[kStatBox];
+    out->tri_tests = h[kStatTri];
     out->kernel_ms = ctx->kernel_ms;
     out->launches = ctx->launches;
     out->variant = ctx->has_scene ? (uint32_t)ctx->S.variant : 0u;

@@ -46,6 +46,24 @@ __device__ __forceinline__ void prof_add(const ProfAcc& p, int idx, unsigned lon
 #define PROF_ITER(id)
 #endif
 
+// Diagnostic build only (-DHPT_COUNT_TESTS, `make count`): every lane counts the box and
+// triangle tests it executes (a test the back-face filter settles counts as a triangle test);
+// the kernels add the totals to two more statistics slots.  The product build compiles none of it.
+#ifdef HPT_COUNT_TESTS
+struct TestCount {
+    unsigned long long box, tri;
+};
+#define COUNT_ARG , TestCount& tcount
+#define COUNT_PASS , tcount
+#define COUNT_BOX(n) (tcount.box += (n))
+#define COUNT_TRI(n) (tcount.tri += (n))
+#else
+#define COUNT_ARG
+#define COUNT_PASS
+#define COUNT_BOX(n)
+#define COUNT_TRI(n)
+#endif
+
 // ---------------------------------------------------------------- vec3 ------
 // glm::vec3 semantics (external/glm/detail/func_geometric.inl:54-96):
 // dot = (x*x' + y*y') + z*z', cross as written there, normalize = v * (1/sqrt(dot)).
@@ -444,7 +462,7 @@ HD TriQueue make_tri_queue(uint32_t* base) {
 }
 
 template <int kScene, bool kShadow>
-HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3 o, f3 d, double tmax, int& hit_tri, double& hit_t PROF_ARG) {
+HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3 o, f3 d, double tmax, int& hit_tri, double& hit_t PROF_ARG COUNT_ARG) {
     const float4* N;
     const float4* T;
     if constexpr (kScene == kScenePairLds) {
@@ -487,6 +505,7 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
             const uint32_t stop = at + table[oct] * 32u;
             while (at < stop) {
                 PROF_ITER(kShadow ? kProfBoxS : kProfBoxC);
+                COUNT_BOX(1);
                 const float4 nr = lds_read(at), fr = lds_read(at + 16u);
                 // Bounds3::IntersectP with the planes already ordered; equals box_hit for finite reciprocals
                 const float tnear = fmaxf(fmaxf((nr.x - o.x) * inv.x, (nr.y - o.y) * inv.y), (nr.z - o.z) * inv.z);
@@ -506,6 +525,7 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
             uint32_t at = nbase + 8u * copy_bytes;
             const uint32_t stop = at + copy_bytes;
             while (at < stop) {
+                COUNT_BOX(1);
                 const float4 lo = lds_read(at), hi = lds_read(at + 16u);
                 const bool hit = box_hit(lo, hi, o, inv, nx, ny, nz);
                 if constexpr (kMask32) {
@@ -528,6 +548,7 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
                 const int tri = __ffs((int)m) - 1;
                 const float4 nr = T[4 * tri + 3];
                 const uint32_t group = __float_as_uint(nr.w);
+                COUNT_TRI(dot(d, xyz(nr)) > 0 ? 1 : 0);  // a triangle rejected here never reaches the loop below
                 if (dot(d, xyz(nr)) > 0) pending &= ~group;
                 m &= ~group;
             }
@@ -535,12 +556,14 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
             for (mask_t m = undecided; m;) {
                 const int tri = __ffsll((long long)m) - 1;
                 const mask_t rest = m & (m - 1);
+                COUNT_TRI(dot(d, xyz(T[4 * tri + 3])) > 0 ? 1 : 0);
                 if (dot(d, xyz(T[4 * tri + 3])) > 0) pending ^= m ^ rest;  // m ^ rest = the bit just examined
                 m = rest;
             }
         }
         while (pending) {
             PROF_ITER(kShadow ? kProfTriS : kProfTriC);
+            COUNT_TRI(1);
             const int tri = kMask32 ? __ffs((int)pending) - 1 : __ffsll((long long)pending) - 1;
             pending &= pending - 1;
             double t;
@@ -588,8 +611,10 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
             cur = (finite ? box_hit_finite(rlo, rhi, o, inv) : box_hit(rlo, rhi, o, inv, nx, ny, nz)) ? 0 : -1;
         }
         uint32_t cnt = 0, sp = 0;
+        COUNT_BOX(1);  // the root's box
         for (;;) {
             while (cur >= 0 && cnt + 2u <= kQueue) {
+                COUNT_BOX(2);
                 const float4 q0 = N[4 * cur], q1 = N[4 * cur + 1], q2 = N[4 * cur + 2], q3 = N[4 * cur + 3];
                 bool hl, hr;
                 float tnl = 0.f, tnr = 0.f;
@@ -648,6 +673,7 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
             for (uint32_t k = 0; k < cnt; ++k) {
                 const int tri = (int)tq.q[k * tq.stride];
                 double t;
+                COUNT_TRI(1);
                 if (tri_hit(T, tri, o, d, t)) {
                     if constexpr (kShadow) {
                         if (t < limit) {
@@ -679,6 +705,7 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
         uint32_t cnt = 0;
         for (;;) {
             while (node < end && cnt < kTriQueue) {
+                COUNT_BOX(1);
                 const float4 lo = N[2 * node], hi = N[2 * node + 1];
                 const bool hit = finite ? box_hit_finite(lo, hi, o, inv) : box_hit(lo, hi, o, inv, nx, ny, nz);
                 const int tri = __float_as_int(hi.w);
@@ -692,6 +719,7 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
             for (uint32_t k = 0; k < cnt; ++k) {
                 const int tri = (int)tq.q[k * tq.stride];
                 double t;
+                COUNT_TRI(1);
                 if (tri_hit(T, tri, o, d, t)) {
                     if constexpr (kShadow) {
                         if (t < limit) {
@@ -930,7 +958,7 @@ HD void generate_camera_path(const DevScene& S, uint32_t pixel, uint32_t sample,
 // the caller ends it after max_depth bounces otherwise.  Counts shadow queries.
 template <int kScene, bool kGlass, uint32_t kShadowInc = 1u>
 HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, Path& p, int hit_tri, double hit_t,
-                     uint32_t& shadow_queries PROF_ARG) {
+                     uint32_t& shadow_queries PROF_ARG COUNT_ARG) {
     bool alive = true;
 #ifdef HPT_PROFILE
     unsigned long long prof_s0 = __builtin_readcyclecounter();
@@ -1010,7 +1038,7 @@ HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, TriQueue
 #ifdef HPT_PROFILE
                 prof_add(prof, kProfShadeA, __builtin_readcyclecounter() - prof_s0);
 #endif
-                trace<kScene, true>(S, lds, tq, so, wi, (double)length(px), occ_tri, occ_t PROF_PASS);
+                trace<kScene, true>(S, lds, tq, so, wi, (double)length(px), occ_tri, occ_t PROF_PASS COUNT_PASS);
 #ifdef HPT_PROFILE
                 prof_s0 = __builtin_readcyclecounter();
                 PROF_ITER(kProfShadeB);

@@ -114,6 +114,8 @@ typedef struct {
                                  1 the same from LDS, 2/3 LDS with a 32-/64-bit leaf mask,
                                  5 two-child records + stack through L1/L2, 6 the same from LDS,
                                  7 two-child records with distance culling (HPT_TRAVERSAL_CULLED)   */
+    uint64_t box_tests;       /* box / triangle tests the kernels executed: counted only by the diagnostic     */
+    uint64_t tri_tests;       /* build of the library (-DHPT_COUNT_TESTS, `make count`); 0 in the product build */
 } hpt_stats;
 
 const char* hpt_last_error(void);
