@@ -512,6 +512,181 @@ k_wf_bounces(DevScene S, int max_depth, uint32_t seg, WfQueue q0, WfQueue q1, co
     COUNT_FLUSH(stats);
 }
 
+// ---- wave scheduler (scenes read through two-child records) -----------------
+// In the kernels above a lane traces its ray from start to end inside trace<>, so a wave walks
+// until its slowest lane is done: on the bunny and the height fields only a fifth of the VALU
+// lanes were active (PMC).  Here every lane carries a small state machine
+//     IDLE -> WALK(closest) -> SHADE_A -> WALK(any-hit) -> SHADE_B -> IDLE | WALK(closest)
+// and the WAVE decides what to run next from how many lanes want what: a round of box steps
+// (walk_step) for the lanes that can step, a round of triangle tests for the lanes whose queue
+// is full or whose walk has ended, the first or second half of the shading for the lanes that
+// wait for it, or a refill of the idle lanes with new paths.  A kind of round runs when enough
+// lanes want it (thresholds below); when none reaches its threshold the most wanted one runs, so
+// some lane always advances.  A lane whose ray ends early no longer idles to the end of the
+// slowest ray of its wave: its next ray joins the following rounds.
+#ifndef HPT_SM_T_STEP
+#define HPT_SM_T_STEP 24
+#endif
+#ifndef HPT_SM_T_TRI
+#define HPT_SM_T_TRI 12
+#endif
+#ifndef HPT_SM_T_SHADE
+#define HPT_SM_T_SHADE 32
+#endif
+#ifndef HPT_SM_T_REFILL
+#define HPT_SM_T_REFILL 24
+#endif
+enum { kLaneIdle = 0, kLaneWalk = 1, kLaneShadeA = 2, kLaneShadeB = 3 };
+
+// All bounces of a segment's paths, like k_wf_bounces, for the pair variants.
+#ifndef HPT_SM_WAVES
+#define HPT_SM_WAVES 1
+#endif
+template <int kScene, bool kGlass>
+__global__ void __launch_bounds__(256, HPT_SM_WAVES)
+k_wf_bounces_sm(DevScene S, int max_depth, uint32_t seg, WfQueue q0, WfQueue q1, const uint32_t* __restrict__ live,
+                int64_t* __restrict__ accum, unsigned long long* __restrict__ stats) {
+    extern __shared__ float4 lds[];
+    __shared__ uint32_t s_out, s_next;
+    uint32_t count = live[blockIdx.x];
+    if (count == 0) return;
+    stage_scene<kScene>(S, lds);
+    const uint32_t lane = threadIdx.x & 63u;
+    const size_t seg_base = (size_t)blockIdx.x * seg;
+    const TriQueue tq = make_tri_queue<kScene>(reinterpret_cast<uint32_t*>(lds + S.lds_float4s));
+    const float4* N = kScene == kScenePairLds ? lds : S.pairs;
+    const float4* T = kScene == kScenePairLds ? lds + 4u * S.num_pairs : S.tris;
+    uint32_t n_closest = 0, n_shadow = 0;
+    COUNT_DECL;
+    for (int bounce = 0; bounce < max_depth && count; ++bounce) {
+        const WfQueue& q_in = (bounce & 1) ? q1 : q0;
+        const WfQueue& q_out = (bounce & 1) ? q0 : q1;
+        if (threadIdx.x == 0) {
+            s_out = 0;
+            s_next = 0;
+        }
+        __syncthreads();  // also: the records the previous bounce stored are visible to the whole workgroup
+        int st = kLaneIdle;
+        bool more = true;  // wave-uniform: the segment may still hold records nobody has taken
+        Path p;
+        Walk W;
+        W.cur = -1;
+        W.cnt = 0u;
+        int hit_tri = -1;
+        double hit_t = 0.0;
+        LightSample ls{};
+        bool lit = false;  // kLaneShadeB: a shadow ray was traced (its answer is in W)
+        for (;;) {
+            const bool walking = st == kLaneWalk;
+            const bool can_step = walking && walk_can_step<kScene>(W);
+            const bool wants_tri = walking && !can_step && W.cnt > 0u;
+            const uint32_t c_step = (uint32_t)__popcll(__ballot(can_step));
+            const uint32_t c_tri = (uint32_t)__popcll(__ballot(wants_tri));
+            const uint32_t c_a = (uint32_t)__popcll(__ballot(st == kLaneShadeA));
+            const uint32_t c_b = (uint32_t)__popcll(__ballot(st == kLaneShadeB));
+            const unsigned long long m_idle = __ballot(st == kLaneIdle);
+            const uint32_t c_idle = more ? (uint32_t)__popcll(m_idle) : 0u;
+            // what to run: the first kind of round that reaches its threshold, else the most wanted
+            int what;  // 0 refill, 1 step, 2 triangles, 3 shade A, 4 shade B
+            if (c_idle >= HPT_SM_T_REFILL) what = 0;
+            else if (c_step >= HPT_SM_T_STEP) what = 1;
+            else if (c_tri >= HPT_SM_T_TRI) what = 2;
+            else if (c_b >= HPT_SM_T_SHADE) what = 4;
+            else if (c_a >= HPT_SM_T_SHADE) what = 3;
+            else {
+                uint32_t best = c_step;
+                what = 1;
+                if (c_tri > best) { best = c_tri; what = 2; }
+                if (c_b > best) { best = c_b; what = 4; }
+                if (c_a > best) { best = c_a; what = 3; }
+                if (c_idle > best) { best = c_idle; what = 0; }
+                if (best == 0u) break;  // every lane idle and the segment empty
+            }
+            if (what == 0) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&s_next, c_idle);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (base + c_idle >= count) more = false;
+                if (st == kLaneIdle) {
+                    const uint32_t i = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m_idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_idle, 0u));
+                    if (i < count) {
+                        const WfRecord cur = wf_fetch(q_in, seg_base, i, count);
+                        wf_unpack(cur, p);
+                        if (p.pixel != 0xFFFFFFFFu) {  // not a dead record
+                            ++n_closest;
+                            walk_begin<kScene>(S, W, p.o, p.d, false, 0.f COUNT_PASS);
+                            st = walk_done(W) ? kLaneShadeA : kLaneWalk;
+                            hit_tri = -1;
+                            hit_t = (double)kInfinity;
+                        }
+                    }
+                }
+            } else if (what == 1) {
+                // rounds of box steps while enough lanes take part
+                do {
+                    if (st == kLaneWalk && walk_can_step<kScene>(W)) walk_step<kScene>(S, N, tq, W COUNT_PASS);
+                } while ((uint32_t)__popcll(__ballot(st == kLaneWalk && walk_can_step<kScene>(W))) >= HPT_SM_T_STEP);
+            } else if (what == 2) {
+                // rounds of triangle tests: every lane with a queued triangle takes part (the lanes that
+                // could still step as well: the round costs the same), until too few lanes are blocked
+                do {
+                    if (st == kLaneWalk && W.cnt > 0u) walk_test_one<kScene>(S, T, tq, W COUNT_PASS);
+                } while ((uint32_t)__popcll(__ballot(st == kLaneWalk && !walk_can_step<kScene>(W) && W.cnt > 0u)) >= HPT_SM_T_TRI);
+            } else if (what == 3) {
+                if (st == kLaneShadeA) {
+                    f3 so, wi;
+                    float tmax;
+                    const int rc = shade_a(S, p, hit_tri, hit_t, so, wi, tmax, ls);
+                    if (rc == kShadeMiss) {
+                        accumulate_pixel(accum, p.pixel, p.rad);
+                        st = kLaneIdle;
+                    } else if (rc == kShadeShadowRay) {
+                        ++n_shadow;
+                        walk_begin<kScene>(S, W, so, wi, true, tmax COUNT_PASS);
+                        lit = true;
+                        st = walk_done(W) ? kLaneShadeB : kLaneWalk;
+                    } else {
+                        lit = false;
+                        st = kLaneShadeB;
+                    }
+                }
+            } else {
+                bool keep = false;
+                if (st == kLaneShadeB) {
+                    shade_b<kGlass>(S, p, hit_tri, hit_t, lit && W.best < 0, W.d, ls);
+                    keep = p.depth < max_depth;
+                    if (!keep) accumulate_pixel(accum, p.pixel, p.rad);
+                    st = kLaneIdle;
+                }
+                const unsigned long long mask = __ballot(keep);
+                if (mask) {
+                    const int leader = __ffsll((long long)mask) - 1;
+                    uint32_t slot = 0;
+                    if ((int)lane == leader) slot = atomicAdd(&s_out, (uint32_t)__popcll(mask));
+                    slot = __shfl(slot, leader);
+                    if (keep) wf_store(q_out, seg_base + slot + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)), p);
+                }
+            }
+            // walks that have just ended hand their lane to the shading
+            if (st == kLaneWalk && walk_done(W)) {
+                if (W.shadow) {
+                    st = kLaneShadeB;
+                } else {
+                    hit_tri = W.best;
+                    hit_t = W.best_t;
+                    st = kLaneShadeA;
+                }
+            }
+        }
+        __syncthreads();
+        count = s_out;  // survivors = the next bounce's paths
+        __syncthreads();
+    }
+    stat_add(stats + kStatClosest, n_closest);
+    stat_add(stats + kStatShadow, n_shadow);
+    COUNT_FLUSH(stats);
+}
+
 __global__ void k_resolve(const int64_t* __restrict__ accum, size_t n, double denom, float* __restrict__ rgb) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
@@ -1097,8 +1272,17 @@ int render_launch(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sam
         const uint64_t cap = cap_limit < total ? cap_limit : ((total + 63ull) & ~63ull);
         // one queue segment per workgroup; exactly the workgroups that are resident at once
         int per_cu = 0;
+        // scenes read through two-child records run the wave scheduler (HPT_WF_SCHEDULER=0: the plain loop, for A/B runs)
+        const bool pair_variant = S.variant == kScenePair || S.variant == kScenePairLds || S.variant == kScenePairCull;
+        const char* sched_env = getenv("HPT_WF_SCHEDULER");
+        const bool scheduler = pair_variant && !(sched_env && atoi(sched_env) == 0);
         HPT_DISPATCH_RENDER(S.variant, ctx->has_glass, {
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_bounces<kS, kG>, wblock, lds_bytes(S, wblock)));
+            if constexpr (kS == kScenePair || kS == kScenePairLds || kS == kScenePairCull) {
+                if (scheduler) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_bounces_sm<kS, kG>, wblock, lds_bytes(S, wblock)));
+                else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_bounces<kS, kG>, wblock, lds_bytes(S, wblock)));
+            } else {
+                HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_bounces<kS, kG>, wblock, lds_bytes(S, wblock)));
+            }
         })
         if (per_cu < 1) return fail(HPT_ERR_INVALID_ARGUMENT, "the wavefront kernel does not fit a compute unit with %u bytes of LDS", lds_bytes(S, wblock));
         const uint64_t cap_groups = (cap + 63ull) >> 6;
@@ -1127,7 +1311,12 @@ int render_launch(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sam
             hipLaunchKernelGGL(k_wf_generate, dim3(segments), dim3(gblock), 0, stream, S, sample_begin, first, count, (uint32_t)lanes, seg, q[0], live, ctx->d_stats);
             HIP_TRY(hipGetLastError());
             HPT_DISPATCH_RENDER(S.variant, ctx->has_glass, {
-                hipLaunchKernelGGL((k_wf_bounces<kS, kG>), dim3(segments), dim3(wblock), lds_bytes(S, wblock), stream, S, max_depth, seg, q[0], q[1], live, accum, ctx->d_stats);
+                if constexpr (kS == kScenePair || kS == kScenePairLds || kS == kScenePairCull) {
+                    if (scheduler) hipLaunchKernelGGL((k_wf_bounces_sm<kS, kG>), dim3(segments), dim3(wblock), lds_bytes(S, wblock), stream, S, max_depth, seg, q[0], q[1], live, accum, ctx->d_stats);
+                    else hipLaunchKernelGGL((k_wf_bounces<kS, kG>), dim3(segments), dim3(wblock), lds_bytes(S, wblock), stream, S, max_depth, seg, q[0], q[1], live, accum, ctx->d_stats);
+                } else {
+                    hipLaunchKernelGGL((k_wf_bounces<kS, kG>), dim3(segments), dim3(wblock), lds_bytes(S, wblock), stream, S, max_depth, seg, q[0], q[1], live, accum, ctx->d_stats);
+                }
             })
             HIP_TRY(hipGetLastError());
             launches += 2;

@@ -447,8 +447,11 @@ constexpr uint32_t kTriQueue = 8;
 // long as the lane with the most candidates needs): 16 entries measured best for the reference
 // walk (+13 % on the bunny over 8, 24 is slower again: LDS per wave), 12 for the culled one,
 // which wants its hits early.
+#ifndef HPT_PAIR_QUEUE
+#define HPT_PAIR_QUEUE 16
+#endif
 __host__ __device__ constexpr uint32_t tri_queue_entries(int scene) {
-    return (scene == kScenePair || scene == kScenePairLds) ? 16u : scene == kScenePairCull ? 12u : kTriQueue;
+    return (scene == kScenePair || scene == kScenePairLds) ? (uint32_t)HPT_PAIR_QUEUE : scene == kScenePairCull ? 12u : kTriQueue;
 }
 struct TriQueue {
     uint32_t* q;
@@ -742,6 +745,145 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
     }
     hit_tri = best;
     hit_t = best_t;
+}
+
+// ---- resumable traversal of the two-child records ---------------------------
+// The depth-first walk of trace<kScenePair...> cut into pieces a wave scheduler can interleave
+// between lanes: walk_begin (root test), walk_step (one record: two box tests), walk_test_one
+// (one queued triangle).  Same box tests, same triangles tested, same closest-hit rule (lowest
+// t, then lowest leaf-order index) as trace<>; only the order of the triangle tests differs,
+// which no closest-hit result and no occlusion answer depends on.  Closest and any-hit rays
+// share the code (`shadow` is per lane), so one wave can advance both kinds at once.
+struct Walk {
+    f3 o, d, inv;
+    int cur;            // record to visit next, -1 = none left
+    uint32_t sp, cnt;   // stack entries, queued triangles
+    int best;           // closest: best triangle so far; any-hit: the occluder found
+    double best_t;
+    float tmax;         // any-hit: Ray::shadowDistance (a float's value, Scene.hpp:203)
+    float cull_t;       // kScenePairCull only
+    bool finite, shadow;
+};
+template <int kScene>
+HD bool walk_can_step(const Walk& W) { return W.cur >= 0 && W.cnt + 2u <= tri_queue_entries(kScene); }
+HD bool walk_done(const Walk& W) { return W.cur < 0 && W.cnt == 0u; }
+
+template <int kScene>
+HD void walk_begin(const DevScene& S, Walk& W, f3 o, f3 d, bool shadow, float tmax COUNT_ARG) {
+    constexpr bool kCull = (kScene == kScenePairCull);
+    W.o = o;
+    W.d = d;
+    W.inv = mk(rcp_rn(d.x), rcp_rn(d.y), rcp_rn(d.z));  // == float(1. / double(d)), Ray.hpp:21
+    const float kInf = __builtin_inff();
+    W.finite = fabsf(W.inv.x) < kInf && fabsf(W.inv.y) < kInf && fabsf(W.inv.z) < kInf;
+    W.shadow = shadow;
+    W.tmax = tmax;
+    W.best = -1;
+    W.best_t = (double)kInfinity;
+    W.sp = 0u;
+    W.cnt = 0u;
+    W.cull_t = shadow ? (float)((double)tmax - (double)kEpsilon4) * 1.000001f + S.cull_slack : kInf;
+    const float4 rlo = make_float4(S.root_lo[0], S.root_lo[1], S.root_lo[2], 0.f);
+    const float4 rhi = make_float4(S.root_hi[0], S.root_hi[1], S.root_hi[2], 0.f);
+    COUNT_BOX(1);
+    bool hit;
+    if (kCull && W.finite) {
+        float tn, tf;
+        hit = box_range_finite(rlo, rhi, o, W.inv, tn, tf) && tf >= -S.cull_slack && tn <= W.cull_t;
+    } else {
+        hit = W.finite ? box_hit_finite(rlo, rhi, o, W.inv) : box_hit(rlo, rhi, o, W.inv, d.x < 0, d.y < 0, d.z < 0);
+    }
+    W.cur = hit ? 0 : -1;
+}
+
+// visit record W.cur (requires walk_can_step): test both children's boxes, queue the leaves that
+// are hit, descend into / push the interior children that are hit, else pop
+template <int kScene>
+HD void walk_step(const DevScene& S, const float4* __restrict__ N, TriQueue tq, Walk& W COUNT_ARG) {
+    constexpr bool kCull = (kScene == kScenePairCull);
+    const bool cull = kCull && W.finite;
+    const float behind = -S.cull_slack;
+    const f3 o = W.o, inv = W.inv;
+    COUNT_BOX(2);
+    const float4 q0 = N[4 * W.cur], q1 = N[4 * W.cur + 1], q2 = N[4 * W.cur + 2], q3 = N[4 * W.cur + 3];
+    bool hl, hr;
+    float tnl = 0.f, tnr = 0.f;
+    if (cull) {
+        float tfl, tfr;
+        hl = box_range_finite(q0, q1, o, inv, tnl, tfl) && tfl >= behind && tnl <= W.cull_t;
+        hr = box_range_finite(q2, q3, o, inv, tnr, tfr) && tfr >= behind && tnr <= W.cull_t;
+    } else if (W.finite) {
+        hl = box_hit_finite(q0, q1, o, inv);
+        hr = box_hit_finite(q2, q3, o, inv);
+    } else {
+        const bool nx = W.d.x < 0, ny = W.d.y < 0, nz = W.d.z < 0;
+        hl = box_hit(q0, q1, o, inv, nx, ny, nz);
+        hr = box_hit(q2, q3, o, inv, nx, ny, nz);
+    }
+    const int rl = __float_as_int(q0.w), rr = __float_as_int(q1.w);
+    if (hl && rl < 0) {
+        tq.q[W.cnt * tq.stride] = (uint32_t)~rl;
+        ++W.cnt;
+    }
+    if (hr && rr < 0) {
+        tq.q[W.cnt * tq.stride] = (uint32_t)~rr;
+        ++W.cnt;
+    }
+    const bool gl = hl && rl >= 0, gr = hr && rr >= 0;
+    if (gl && gr) {
+        if constexpr (kCull) {
+            const bool right_first = tnr < tnl;
+            const float tfar_child = right_first ? tnl : tnr;
+            const uint32_t qd = (uint32_t)fminf(fmaxf(tfar_child, 0.f) * S.cull_qscale, 1023.f);
+            tq.stk[W.sp * tq.stride] = (uint32_t)(right_first ? rl : rr) | (qd << 22);
+            W.cur = right_first ? rr : rl;
+        } else {
+            tq.stk[W.sp * tq.stride] = (uint32_t)rr;
+            W.cur = rl;
+        }
+        ++W.sp;
+    } else if (gl) {
+        W.cur = rl;
+    } else if (gr) {
+        W.cur = rr;
+    } else {
+        W.cur = -1;
+        while (W.sp) {
+            --W.sp;
+            uint32_t e = tq.stk[W.sp * tq.stride];
+            if constexpr (kCull) {
+                if ((float)(e >> 22) * S.cull_qinv > W.cull_t) continue;
+                e &= 0x3FFFFFu;
+            }
+            W.cur = (int)e;
+            break;
+        }
+    }
+}
+
+// test the triangle queued last (requires W.cnt > 0)
+template <int kScene>
+HD void walk_test_one(const DevScene& S, const float4* __restrict__ T, TriQueue tq, Walk& W COUNT_ARG) {
+    constexpr bool kCull = (kScene == kScenePairCull);
+    --W.cnt;
+    const int tri = (int)tq.q[W.cnt * tq.stride];
+    double t;
+    COUNT_TRI(1);
+    if (tri_hit(T, tri, W.o, W.d, t)) {
+        if (W.shadow) {
+            if (t < (double)W.tmax - (double)kEpsilon4) {  // BVH.hpp:121-127: occluded, the query ends
+                W.best = tri;
+                W.best_t = t;
+                W.cur = -1;
+                W.sp = 0u;
+                W.cnt = 0u;
+            }
+        } else if (t < W.best_t || (t == W.best_t && tri < W.best)) {
+            W.best = tri;
+            W.best_t = t;
+            if constexpr (kCull) W.cull_t = (float)t * 1.000001f + S.cull_slack;
+        }
+    }
 }
 
 // -------------------------------------------------------------- shading -----
@@ -1086,6 +1228,123 @@ HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, TriQueue
     if (isnan(p.rad.x) || isnan(p.rad.y) || isnan(p.rad.z) || isinf(p.rad.x) || isinf(p.rad.y) || isinf(p.rad.z))
         p.rad = mk(0.0f);
     return alive;
+}
+
+// Scene::TracePath cut in two at its shadow query, for the wave scheduler: shade_a is
+// :156-203 (miss, emission, light sample, the shadow ray), shade_b is :205-271 (the direct-light
+// term once the occlusion answer is known, BSDF sample, depth++ and the NaN reset).  The
+// expressions are those of shade_bounce, operation for operation.
+struct LightSample {
+    float lightPdf, lightSamplePdf, cos_theta_prime, r2;
+    uint32_t light;
+};
+enum { kShadeMiss = 0, kShadeShadowRay = 1, kShadeNoShadowRay = 2 };
+HD void finish_bounce(Path& p) {  // :268-271
+    p.depth++;
+    if (isnan(p.rad.x) || isnan(p.rad.y) || isnan(p.rad.z) || isinf(p.rad.x) || isinf(p.rad.y) || isinf(p.rad.z))
+        p.rad = mk(0.0f);
+}
+HD int shade_a(const DevScene& S, Path& p, int hit_tri, double hit_t, f3& so, f3& wi, float& tmax, LightSample& ls) {
+    if (hit_tri < 0) {
+        finish_bounce(p);
+        return kShadeMiss;
+    }
+    const f3 coords = p.o + p.d * (float)hit_t;  // Ray::operator(), Ray.hpp:27
+    {
+        const DevMaterial& material = S.mats[__float_as_int(S.tris[4 * hit_tri + 1].w)];
+        if (material.flags & kMatEmitting) {  // :164-184
+            const f3 radiance = mk(material.emission[0], material.emission[1], material.emission[2]);
+            if (p.depth == 0 || p.specular) {
+                p.rad = p.rad + p.thr * radiance;
+            } else {
+                const float weight = powerHeuristic(p.pdf, S.tris[4 * hit_tri].w);
+                p.rad = p.rad + p.thr * radiance * weight;
+            }
+        }
+    }
+    if (p.specular) return kShadeNoShadowRay;
+    // Scene::sampleLight (:99-120)
+    const u4 ra = philox4x32_10((uint32_t)p.depth, 0u, S.seed, 0u, p.pixel, p.sample);
+    float lightSamplePdf = 0.0f, lightPdf = 0.0f;
+    f3 lx = mk(0.f), ln = mk(0.f);
+    uint32_t light = 0;
+    {
+        const float pick = u01(ra.x) * S.sum_light_area;
+        float emit_area_sum = 0;
+        for (uint32_t k = 0; k < S.num_lights; ++k) {
+            const DevLight& L = S.lights[k];
+            emit_area_sum += L.area;
+            if (pick <= emit_area_sum) {
+                // BVHAccel::Sample / getSample (BVH.hpp:147-184)
+                float q = sqrt_rn(u01(ra.y)) * L.root_area;
+                uint32_t node = L.root_node;
+                int tri;
+                while ((tri = __float_as_int(S.nodes[2 * node + 1].w)) < 0) {
+                    const uint32_t left = node + 1;
+                    const float la = S.node_area[left];
+                    if (q < la) node = left;
+                    else {
+                        q -= la;
+                        node = (uint32_t)__float_as_int(S.nodes[2 * left].w);
+                    }
+                }
+                // Triangle::Sample (Triangle.hpp:75-82)
+                const float sx = sqrt_rn(u01(ra.z)), sy = u01(ra.w);
+                const float4 a0 = S.tris[4 * tri], a3 = S.tris[4 * tri + 3];
+                const float4 b1 = S.tri_v12[2 * tri], b2 = S.tri_v12[2 * tri + 1];
+                lx = xyz(a0) * (1.0f - sx) + xyz(b1) * (sx * (1.0f - sy)) + xyz(b2) * (sx * sy);
+                ln = xyz(a3);
+                lightPdf = a0.w;
+                lightSamplePdf = L.inv_root_area;
+                light = k;
+                break;
+            }
+        }
+    }
+    if (!(lightSamplePdf > 0.0f)) return kShadeNoShadowRay;
+    const f3 px = lx - coords;
+    wi = normalize(px);
+    so = coords + wi * kEpsilon5;
+    ls.cos_theta_prime = satDot(ln, -wi);
+    ls.r2 = dot(lx - coords, lx - coords);
+    ls.lightPdf = lightPdf;
+    ls.lightSamplePdf = lightSamplePdf;
+    ls.light = light;
+    tmax = length(px);
+    return kShadeShadowRay;
+}
+// lit: a shadow ray towards the light sample `ls` along `wi` was traced and found nothing
+template <bool kGlass>
+HD void shade_b(const DevScene& S, Path& p, int hit_tri, double hit_t, bool lit, f3 wi_light, const LightSample& ls) {
+    const f3 coords = p.o + p.d * (float)hit_t;
+    const f3 normal = xyz(S.tris[4 * hit_tri + 3]);
+    const DevMaterial& material = S.mats[__float_as_int(S.tris[4 * hit_tri + 1].w)];
+    const f3 wo = -p.d;
+    if (lit) {  // :208-227
+        const DevLight& L = S.lights[ls.light];
+        const f3 lemit = mk(L.emission[0], L.emission[1], L.emission[2]);
+        f3 bsdf;
+        float bsdfPdf;
+        mat_eval<kGlass>(material, wi_light, wo, normal, bsdf, bsdfPdf);
+        const float cos_theta = satDot(normal, wi_light);
+        const float weight = powerHeuristic(ls.lightPdf, bsdfPdf);
+        p.rad = p.rad + p.thr * lemit * bsdf * cos_theta * ls.cos_theta_prime / ls.r2 / ls.lightSamplePdf * weight;
+    }
+    // :230-250
+    const u4 rb = philox4x32_10((uint32_t)p.depth, 1u, S.seed, 0u, p.pixel, p.sample);
+    const f3 wi = mat_sample<kGlass>(material, u01(rb.x), u01(rb.y), u01(rb.z), wo, normal);
+    f3 bsdf;
+    float pdf;
+    mat_eval<kGlass>(material, wi, wo, normal, bsdf, pdf);
+    p.pdf = pdf;
+    if (!(pdf < kEpsilon5)) {  // else the path keeps its ray and re-traces it (:238-240)
+        p.specular = (material.flags & kMatSpecular) != 0;
+        const float cos_theta = absDot(normal, wi);
+        p.thr = p.thr * (bsdf * cos_theta / pdf);
+        p.o = coords + wi * kEpsilon5;
+        p.d = wi;
+    }
+    finish_bounce(p);
 }
 
 #undef HD
