@@ -147,20 +147,25 @@ def main():
     dev_index = int(os.environ.get("HPT_BENCH_DEVICE", local_rank))
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # HPT_BENCH_FORCE_DIST=1: create the process group and run the reduce even with one rank, so that a
+    # one-GPU box exercises the RCCL path (communicator, int64 reduce on device memory) that N ranks take
+    use_dist = world > 1 or os.environ.get("HPT_BENCH_FORCE_DIST", "0") not in ("", "0")
+    if use_dist:
+        # the host driver of this pool only supports dmabuf IPC; RCCL's buffer sharing needs it switched on
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
 
+    from cudapathtracer_amd.sharding import reduce_accum
+
     def reduce_sum(t):
-        if backend == "nccl":
-            dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
-        else:  # rehearsal path only
-            h = t.cpu()
-            dist.reduce(h, dst=0, op=dist.ReduceOp.SUM)
-            t.copy_(h)
+        reduce_accum(t, dist, 0)
 
     def all_reduce(t, op):
         if backend == "nccl":
@@ -185,15 +190,17 @@ def main():
     stream = torch.cuda.current_stream()
 
     def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
+        ctx.synchronize()            # the HIP runtime the kernel library launches through
+        torch.cuda.synchronize()     # torch's (the same one when torch was loaded first)
+        if use_dist:
             dist.barrier()
+        ctx.synchronize()
         torch.cuda.synchronize()
 
     # sample ranges: step k of rank r traces samples [(k*world + r)*spp_step, +spp_step)
     total_spp = args.steps * world * spp_step
     warm_base = total_spp  # warm-up samples lie outside the timed range
-    if world > 1:  # warm up the communicator as well
+    if use_dist:  # warm up the communicator as well
         reduce_sum(accum)
     for k in range(args.warmup):
         ctx.render(args.mode, args.block, depth, warm_base + (k * world + rank) * spp_step, spp_step, accum=accum, stream=stream)
@@ -205,7 +212,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         ctx.render(args.mode, args.block, depth, (k * world + rank) * spp_step, spp_step, accum=accum, stream=stream)
-    if world > 1:
+    if use_dist:
         reduce_sum(accum)
     if rank == 0:
         ctx.resolve_dev(total_spp, rgb, accum=accum, stream=stream)
@@ -216,7 +223,7 @@ def main():
     rays = st["closest_queries"] + st["shadow_queries"]
     agg = torch.tensor([float(rays), float(st["paths"]), float(st["closest_queries"])], dtype=torch.float64, device=dev)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         all_reduce(agg, dist.ReduceOp.SUM)
         all_reduce(tmax, dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
@@ -305,12 +312,13 @@ def main():
                                        spp_step, total_spp),
                        "rays_per_path": total_rays / total_paths,
                        "traversal": args.traversal,
-                       "parallelism": "spp-sharded x%d, one RCCL reduce" % world if world > 1 else "1 GPU"},
+                       "parallelism": ("spp-sharded x%d, one %s reduce" % (world, "RCCL" if backend == "nccl" else backend)) if use_dist else "1 GPU",
+                       "collective_backend": (dist.get_backend() if use_dist else None)},
             "roofline": roof,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()

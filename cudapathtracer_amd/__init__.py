@@ -2,5 +2,5 @@
 kevinsadi/CudaPathTracer (Scene / HipRenderer), see api.py."""
 from .api import (Context, HipRenderer, HptError, Material, SavePPM, SavePFM, Scene, SingleKernel, Streamed,  # noqa: F401
                   TRAVERSAL_CULLED, TRAVERSAL_REFERENCE,
-                  device_count, load_libraries)
-from .sharding import render_sharded, sample_range  # noqa: F401
+                  accum_reduce, device_count, load_libraries)
+from .sharding import reduce_accum, render_sharded, sample_range  # noqa: F401

@@ -79,6 +79,14 @@ def load_libraries():
     global _libs
     if _libs is not None:
         return _libs
+    # One HIP runtime per process: PyTorch's ROCm wheels bundle their own libamdhip64 / libhsa-runtime64,
+    # and a process that loads libhpt.so first and torch afterwards ends up with two of each (streams and
+    # synchronisation then belong to different runtimes).  With torch loaded first the kernel library
+    # binds to the runtime that is already there.  Without torch installed the system's runtime is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     # HPT_LIBHPT: load a differently built kernel library (A/B experiments)
     paths = [os.environ.get("HPT_LIBHPT") or os.path.join(_PKG, "libhpt.so"), os.path.join(_PKG, "libhpt_host.so")]
     for p in paths:
@@ -117,6 +125,9 @@ def _declare(L, H):
     L.hpt_stats_get.argtypes = [vp, C.POINTER(hpt_stats)]
     L.hpt_stats_reset.argtypes = [vp]
     L.hpt_accum_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.hpt_accum_reduce.argtypes = [C.POINTER(vp), i32, i32]
+    L.hpt_synchronize.argtypes = [vp]
+    L.hpt_accum_download.argtypes = [vp, vp, vp]
     H.hpt_host_last_error.restype = C.c_char_p
     H.hpt_host_scene_cornell.argtypes = [C.c_char_p, i32, i32, i32, C.POINTER(vp)]
     H.hpt_host_scene_builtin.argtypes = [i32, C.c_char_p, i32, i32, i32, C.POINTER(vp)]
@@ -131,6 +142,7 @@ def _declare(L, H):
     H.hpt_host_bvh_dump.argtypes = [vp, i32, C.POINTER(C.c_int), vp, vp, vp, vp]
     H.hpt_host_render.argtypes = [vp, i32, i32, i32, i32, i32, vp, C.POINTER(hpt_stats)]
     H.hpt_host_render_iterative.argtypes = [vp, i32, i32, i32, i32, i32, vp, C.POINTER(hpt_stats)]
+    H.hpt_host_render_devices.argtypes = [vp, C.POINTER(C.c_int), i32, i32, i32, i32, i32, i32, vp, C.POINTER(hpt_stats)]
     H.hpt_host_save_ppm.argtypes = [C.c_char_p, vp, i32, i32]
     H.hpt_host_save_pfm.argtypes = [C.c_char_p, vp, i32, i32]
 
@@ -261,11 +273,17 @@ class Scene:
                                        m.ctypes.data))
         return dict(bounds=b, payload=p, area=a, miss=m)
 
-    def render_cpp(self, spp, max_depth, num_threads=256, mode=SingleKernel, device=0, iterative=False):
+    def render_cpp(self, spp, max_depth, num_threads=256, mode=SingleKernel, device=0, iterative=False, devices=None):
         """Render through the C++ HipRenderer class: PrepareRender/Render/FinishRender, or
-        (iterative) PrepareRender, PathTrace(scene, iter) spp times, FinishRender."""
+        (iterative) PrepareRender, PathTrace(scene, iter) spp times, FinishRender.
+        devices: list of GPU indices to shard the samples over (HipRenderer::devices)."""
         rgb = np.zeros((self.width * self.height, 3), np.float32)
         st = hpt_stats()
+        if devices is not None:
+            arr = (C.c_int * len(devices))(*devices)
+            _ckh(self._H.hpt_host_render_devices(self._h, arr, len(devices), spp, max_depth, num_threads, mode,
+                                                 1 if iterative else 0, rgb.ctypes.data, C.byref(st)))
+            return rgb, st.as_dict()
         fn = self._H.hpt_host_render_iterative if iterative else self._H.hpt_host_render
         _ckh(fn(self._h, device, spp, max_depth, num_threads, mode, rgb.ctypes.data, C.byref(st)))
         return rgb, st.as_dict()
@@ -329,6 +347,16 @@ class Context:
 
     def resolve_dev(self, spp_total, rgb_dev, accum=None, stream=None):
         _ck(self._L.hpt_resolve_dev(self._h, _ptr(accum), int(spp_total), _ptr(rgb_dev), _stream(stream)))
+
+    def synchronize(self):
+        """Wait for everything queued on this context's GPU (in the HIP runtime the library uses)."""
+        _ck(self._L.hpt_synchronize(self._h))
+
+    def accum_download(self, accum=None):
+        """The exact int64 accumulators as numpy (pixels, 3)."""
+        out = np.zeros((self.width * self.height, 3), np.int64)
+        _ck(self._L.hpt_accum_download(self._h, _ptr(accum), out.ctypes.data))
+        return out
 
     def accum_buffer(self):
         p, n = C.c_void_p(), C.c_size_t()
@@ -443,6 +471,13 @@ def SavePFM(path, framebuffer, width, height):
     """Utility::SavePFM: linear float RGB as a portable float map (not in the reference)."""
     rgb = np.ascontiguousarray(framebuffer, np.float32)
     _ckh(load_libraries()[1].hpt_host_save_pfm(os.fspath(path).encode(), rgb.ctypes.data, int(width), int(height)))
+
+
+def accum_reduce(contexts, root=0):
+    """hpt_accum_reduce: sum the contexts' own accumulation buffers into contexts[root]'s (one process
+    driving several GPUs; RCCL between distinct devices)."""
+    arr = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
+    _ck(load_libraries()[0].hpt_accum_reduce(arr, len(contexts), int(root)))
 
 
 def device_count():

@@ -16,6 +16,7 @@
 // Small scenes are staged into LDS once per workgroup in a pre-processed form (the Cornell
 // box: 20 KiB), larger ones are read through L1/L2 as two-child records; see DevScene::variant.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -687,6 +688,12 @@ k_wf_bounces_sm(DevScene S, int max_depth, uint32_t seg, WfQueue q0, WfQueue q1,
     COUNT_FLUSH(stats);
 }
 
+// dst += src (two accumulation buffers on one device)
+__global__ void k_accum_add(int64_t* __restrict__ dst, const int64_t* __restrict__ src, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] += src[i];
+}
+
 __global__ void k_resolve(const int64_t* __restrict__ accum, size_t n, double denom, float* __restrict__ rgb) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
@@ -1179,6 +1186,48 @@ int grid_for(const hpt_ctx* ctx, uint64_t work, int block) {
     return (int)(want < cap ? (want ? want : 1) : cap);
 }
 
+// RCCL, bound at the first cross-device reduce (the library has no link-time dependency on it).
+// Only the few entry points hpt_accum_reduce uses; types as in rccl.h (ncclInt64 = 4, ncclSum = 0).
+struct Rccl {
+    void* lib = nullptr;
+    int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
+    int (*CommDestroy)(void* comm) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Reduce)(const void* send, void* recv, size_t count, int dtype, int op, int root, void* comm, hipStream_t stream) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+std::mutex g_rccl_mutex;
+Rccl g_rccl;
+int load_rccl() {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (g_rccl.lib) return HPT_OK;
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void* lib = nullptr;
+    for (const char* n : names)
+        if ((lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!lib) return fail(HPT_ERR_HIP, "cannot load RCCL (librccl.so): %s", dlerror());
+    Rccl r;
+    r.lib = lib;
+    r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(dlsym(lib, "ncclCommInitAll"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(lib, "ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
+    r.Reduce = reinterpret_cast<decltype(r.Reduce)>(dlsym(lib, "ncclReduce"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+    if (!r.CommInitAll || !r.CommDestroy || !r.GroupStart || !r.GroupEnd || !r.Reduce || !r.GetErrorString) {
+        dlclose(lib);
+        return fail(HPT_ERR_HIP, "librccl.so lacks an entry point hpt_accum_reduce needs");
+    }
+    g_rccl = r;
+    return HPT_OK;
+}
+#define RCCL_TRY(expr)                                                                                        \
+    do {                                                                                                      \
+        const int r_ = (expr);                                                                                \
+        if (r_ != 0) return fail(HPT_ERR_HIP, "%s failed: %s", #expr, g_rccl.GetErrorString(r_));             \
+    } while (0)
+
 // Buffers a render needs beyond its inputs and outputs.  nullptr for `fixed` in render_launch =
 // the context's own (the wavefront queues grow on demand); otherwise exactly these are used and
 // nothing is allocated.
@@ -1642,6 +1691,101 @@ int hpt_accum_buffer(hpt_ctx* ctx, int64_t** accum_dev, size_t* num_elements) {
     if (accum_dev) *accum_dev = ctx->d_accum;
     if (num_elements) *num_elements = ctx->accum_elems;
     return HPT_OK;
+}
+
+int hpt_synchronize(hpt_ctx* ctx) {
+    if (!ctx) return fail(HPT_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (int rc = set_device(ctx)) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    return HPT_OK;
+}
+
+int hpt_accum_download(hpt_ctx* ctx, const int64_t* accum_dev, int64_t* accum_host) {
+    if (!ctx || !ctx->has_scene) return fail(HPT_ERR_NO_SCENE, "no scene uploaded");
+    if (!accum_host) return fail(HPT_ERR_INVALID_ARGUMENT, "accum_host is null");
+    if (int rc = set_device(ctx)) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(accum_host, accum_dev ? accum_dev : ctx->d_accum, ctx->accum_elems * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return HPT_OK;
+}
+
+int hpt_accum_reduce(hpt_ctx* const* ctxs, int n, int root) {
+    if (!ctxs || n < 1) return fail(HPT_ERR_INVALID_ARGUMENT, "hpt_accum_reduce: no contexts");
+    if (root < 0 || root >= n) return fail(HPT_ERR_INVALID_ARGUMENT, "root %d not in [0, %d)", root, n);
+    for (int i = 0; i < n; ++i) {
+        if (!ctxs[i] || !ctxs[i]->has_scene) return fail(HPT_ERR_NO_SCENE, "context %d has no scene", i);
+        if (ctxs[i]->accum_elems != ctxs[root]->accum_elems) return fail(HPT_ERR_INVALID_ARGUMENT, "context %d renders another resolution than the root", i);
+        for (int j = 0; j < i; ++j)
+            if (ctxs[j] == ctxs[i]) return fail(HPT_ERR_INVALID_ARGUMENT, "context %d is listed twice", i);
+    }
+    const size_t count = ctxs[root]->accum_elems;
+    // every context's queued renders must have finished before another stream or device reads its buffer
+    for (int i = 0; i < n; ++i) {
+        HIP_TRY(hipSetDevice(ctxs[i]->device));
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    // 1. contexts that share a device are summed there: into the root if it lives on that device,
+    //    else into the first of them (the device's representative)
+    std::vector<int> rep;  // one context index per distinct device
+    for (int i = 0; i < n; ++i) {
+        int r = -1;
+        for (int k : rep)
+            if (ctxs[k]->device == ctxs[i]->device) r = k;
+        if (r < 0) {
+            int pick = i;
+            if (ctxs[root]->device == ctxs[i]->device) pick = root;
+            rep.push_back(pick);
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        int r = -1;
+        for (int k : rep)
+            if (ctxs[k]->device == ctxs[i]->device) r = k;
+        if (r == i) continue;
+        HIP_TRY(hipSetDevice(ctxs[i]->device));
+        const int grid = (int)std::min<size_t>((count + 255) / 256, 4096);
+        hipLaunchKernelGGL(k_accum_add, dim3(grid), dim3(256), 0, nullptr, ctxs[r]->d_accum, ctxs[i]->d_accum, count);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    // 2. one RCCL reduce (sum of int64, associative: the result does not depend on the order) over the
+    //    representatives; a single device needs none (HPT_REDUCE_FORCE_RCCL=1 runs it all the same)
+    const char* force = getenv("HPT_REDUCE_FORCE_RCCL");
+    if (rep.size() == 1 && !(force && atoi(force) != 0)) return HPT_OK;
+    if (int rc = load_rccl()) return rc;
+    const int nd = (int)rep.size();
+    std::vector<int> devs(nd);
+    int root_rank = 0;
+    for (int k = 0; k < nd; ++k) {
+        devs[k] = ctxs[rep[k]]->device;
+        if (rep[k] == root) root_rank = k;
+    }
+    std::vector<void*> comms(nd, nullptr);
+    RCCL_TRY(g_rccl.CommInitAll(comms.data(), nd, devs.data()));
+    int rc = HPT_OK;
+    do {
+        int r = g_rccl.GroupStart();
+        for (int k = 0; k < nd && r == 0; ++k) {
+            if (hipSetDevice(devs[k]) != hipSuccess) { r = -1; break; }
+            int64_t* buf = ctxs[rep[k]]->d_accum;
+            r = g_rccl.Reduce(buf, buf, count, /*ncclInt64*/ 4, /*ncclSum*/ 0, root_rank, comms[k], nullptr);
+        }
+        const int e = g_rccl.GroupEnd();
+        if (r == 0) r = e;
+        if (r != 0) {
+            rc = fail(HPT_ERR_HIP, "RCCL reduce failed: %s", r > 0 ? g_rccl.GetErrorString(r) : "hipSetDevice");
+            break;
+        }
+        for (int k = 0; k < nd; ++k) {
+            if (hipSetDevice(devs[k]) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+                rc = fail(HPT_ERR_HIP, "synchronising device %d after the reduce failed", devs[k]);
+                break;
+            }
+        }
+    } while (false);
+    for (int k = 0; k < nd; ++k)
+        if (comms[k]) (void)g_rccl.CommDestroy(comms[k]);
+    return rc;
 }
 
 int hpt_octant_copies(const hpt_scene_desc* sc, int leaf_bits, float* nodes_out, uint32_t* table_out) {

@@ -4,6 +4,7 @@
 #include <iostream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 
 namespace {
 void check(int rc, const char* what) {
@@ -12,6 +13,7 @@ void check(int rc, const char* what) {
 }  // namespace
 
 HipRenderer::~HipRenderer() {
+    for (hpt_ctx* c : extra_ctx) hpt_context_destroy(c);
     if (ctx) hpt_context_destroy(ctx);
 }
 
@@ -20,14 +22,22 @@ void HipRenderer::SetMode(HipRenderMode m) { mode = m; }
 // scene upload + device buffers (CudaRenderer::PrepareRender, gpu_path_tracer/CudaRenderer.cu:19-35)
 void HipRenderer::PrepareRender(const Scene& scene) {
     num_pixels = scene.width * scene.height;
+    for (hpt_ctx* c : extra_ctx) hpt_context_destroy(c);
+    extra_ctx.clear();
     if (ctx) {
         hpt_context_destroy(ctx);
         ctx = nullptr;
     }
-    check(hpt_context_create(device, &ctx), "hpt_context_create");
-    check(hpt_set_traversal(ctx, traversal), "hpt_set_traversal");
     const hpt_scene_desc desc = scene.describe();
-    check(hpt_scene_upload(ctx, &desc), "hpt_scene_upload");
+    const std::vector<int> devs = devices.empty() ? std::vector<int>{device} : devices;
+    for (size_t k = 0; k < devs.size(); ++k) {  // the scene is replicated on every GPU
+        hpt_ctx* c = nullptr;
+        check(hpt_context_create(devs[k], &c), "hpt_context_create");
+        if (k == 0) ctx = c;
+        else extra_ctx.push_back(c);
+        check(hpt_set_traversal(c, traversal), "hpt_set_traversal");
+        check(hpt_scene_upload(c, &desc), "hpt_scene_upload");
+    }
     framebuffer.assign(num_pixels, Vec3(0.f));
     framebuffer_stale = false;
     next_sample = 0;
@@ -37,6 +47,8 @@ void HipRenderer::PrepareRender(const Scene& scene) {
 void HipRenderer::FinishRender(const Scene&) {
     if (ctx) {
         RefreshFramebuffer();  // samples added by PathTrace since the last download
+        for (hpt_ctx* c : extra_ctx) check(hpt_context_destroy(c), "hpt_context_destroy");
+        extra_ctx.clear();
         check(hpt_context_destroy(ctx), "hpt_context_destroy");
     }
     ctx = nullptr;
@@ -46,6 +58,13 @@ void HipRenderer::FinishRender(const Scene&) {
 // the last download
 void HipRenderer::RefreshFramebuffer() {
     if (!ctx || !framebuffer_stale) return;
+    if (reduce_pending) {
+        std::vector<hpt_ctx*> all{ctx};
+        all.insert(all.end(), extra_ctx.begin(), extra_ctx.end());
+        check(hpt_accum_reduce(all.data(), (int)all.size(), 0), "hpt_accum_reduce");
+        for (hpt_ctx* c : extra_ctx) check(hpt_accum_clear(c, nullptr, nullptr), "hpt_accum_clear");  // their samples now live in ctx
+        reduce_pending = false;
+    }
     check(hpt_resolve(ctx, nullptr, (uint32_t)(this->spp > 0 ? this->spp : 1), &framebuffer[0].x, nullptr), "hpt_resolve");
     framebuffer_stale = false;
 }
@@ -58,8 +77,30 @@ void HipRenderer::Render(const Scene& scene) {
     auto start = std::chrono::system_clock::now();
     {
         check(hpt_accum_clear(ctx, nullptr, nullptr), "hpt_accum_clear");
+        for (hpt_ctx* c : extra_ctx) check(hpt_accum_clear(c, nullptr, nullptr), "hpt_accum_clear");
         if (this->spp > 0) {
-            check(hpt_render(ctx, (int)mode, num_threads, scene.maxDepth, 0u, (uint32_t)this->spp, nullptr, nullptr), "hpt_render");
+            if (extra_ctx.empty()) {
+                check(hpt_render(ctx, (int)mode, num_threads, scene.maxDepth, 0u, (uint32_t)this->spp, nullptr, nullptr), "hpt_render");
+            } else {
+                // contiguous sample ranges, the first spp % G contexts take one more; one host thread per context
+                std::vector<hpt_ctx*> all{ctx};
+                all.insert(all.end(), extra_ctx.begin(), extra_ctx.end());
+                const unsigned G = (unsigned)all.size(), base = (unsigned)this->spp / G, extra = (unsigned)this->spp % G;
+                std::vector<std::string> errors(G);
+                std::vector<std::thread> workers;
+                for (unsigned g = 0; g < G; ++g) {
+                    const unsigned begin = g * base + (g < extra ? g : extra), count = base + (g < extra ? 1u : 0u);
+                    workers.emplace_back([&, g, begin, count]() {
+                        if (count == 0) return;
+                        if (hpt_render(all[g], (int)mode, num_threads, scene.maxDepth, begin, count, nullptr, nullptr) != HPT_OK)
+                            errors[g] = hpt_last_error();  // thread-local message, read on the thread that failed
+                    });
+                }
+                for (std::thread& t : workers) t.join();
+                for (const std::string& e : errors)
+                    if (!e.empty()) throw std::runtime_error("hpt_render: " + e);
+                check(hpt_accum_reduce(all.data(), (int)G, 0), "hpt_accum_reduce");
+            }
             next_sample = (unsigned)this->spp;
             static_assert(sizeof(Vec3) == 3 * sizeof(float), "Vec3 must be three packed floats");
             check(hpt_resolve(ctx, nullptr, (uint32_t)this->spp, &framebuffer[0].x, nullptr), "hpt_resolve");
@@ -82,12 +123,26 @@ void HipRenderer::Render(const Scene& scene) {
 // FinishRender().
 void HipRenderer::PathTrace(const Scene& scene, int iter) {
     if (!ctx) throw std::runtime_error("HipRenderer::PathTrace: PrepareRender has not been called");
-    check(hpt_render(ctx, (int)mode, num_threads, scene.maxDepth, (uint32_t)iter, 1u, nullptr, nullptr), "hpt_render");
+    // several GPUs: sample `iter` goes to context iter mod G (any assignment gives the same sums)
+    hpt_ctx* target = extra_ctx.empty() || iter % (int)(extra_ctx.size() + 1) == 0 ? ctx : extra_ctx[(size_t)(iter % (int)(extra_ctx.size() + 1)) - 1];
+    check(hpt_render(target, (int)mode, num_threads, scene.maxDepth, (uint32_t)iter, 1u, nullptr, nullptr), "hpt_render");
     framebuffer_stale = true;
+    reduce_pending = !extra_ctx.empty();
 }
 
 hpt_stats HipRenderer::Stats() {
     hpt_stats s{};
     if (ctx) check(hpt_stats_get(ctx, &s), "hpt_stats_get");
+    for (hpt_ctx* c : extra_ctx) {  // counters add up over the GPUs; the kernel time is the longest GPU's
+        hpt_stats t{};
+        check(hpt_stats_get(c, &t), "hpt_stats_get");
+        s.closest_queries += t.closest_queries;
+        s.shadow_queries += t.shadow_queries;
+        s.paths += t.paths;
+        s.launches += t.launches;
+        s.box_tests += t.box_tests;
+        s.tri_tests += t.tri_tests;
+        if (t.kernel_ms > s.kernel_ms) s.kernel_ms = t.kernel_ms;
+    }
     return s;
 }

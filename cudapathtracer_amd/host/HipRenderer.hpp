@@ -5,6 +5,8 @@
 // become std::runtime_error carrying hpt_last_error().
 #pragma once
 #include "../../include/hpt.h"
+#include <vector>
+
 #include "Renderer.hpp"
 
 enum HipRenderMode { SingleKernel = 1, Streamed = 2 };
@@ -12,14 +14,22 @@ enum HipRenderMode { SingleKernel = 1, Streamed = 2 };
 class HipRenderer : public Renderer {
 private:
     HipRenderMode mode = HipRenderMode::SingleKernel;
-    hpt_ctx* ctx = nullptr;
+    hpt_ctx* ctx = nullptr;             // the context whose buffer holds the picture (devices[0], or `device`)
+    std::vector<hpt_ctx*> extra_ctx;    // one more context per further entry of `devices`
     int num_pixels = 0;
     unsigned next_sample = 0;
+    bool reduce_pending = false;     // PathTrace has put samples into the other GPUs' buffers
     bool framebuffer_stale = false;  // PathTrace has added samples that `framebuffer` does not show yet
 
 public:
     int num_threads = 256;
     int device = 0;  // the reference always renders on device 0
+    // More than one entry: samples-per-pixel sharded over these GPUs (contiguous sample ranges, one
+    // host thread per GPU), the accumulation buffers summed onto devices[0] with one RCCL reduce
+    // (hpt_accum_reduce); the picture is bit-identical to the single-GPU one.  An index may repeat
+    // (several contexts on one GPU: a rehearsal of the flow on a one-GPU machine).  Empty = {device}.
+    // No counterpart in the reference.
+    std::vector<int> devices;
     // HPT_TRAVERSAL_REFERENCE (0, bit-exact, default) or HPT_TRAVERSAL_CULLED (1, opt-in); no
     // counterpart in the reference
     int traversal = 0;

@@ -9,6 +9,9 @@
 // Optional environment knobs that default to the reference's behaviour:
 //   HPT_WIDTH / HPT_HEIGHT   resolution (the built-in scene is 512x512)
 //   HPT_DEVICE               GPU index (default 0)
+//   HPT_GPUS=N               shard the samples over GPUs 0..N-1 (one RCCL reduce sums the accumulators)
+//   HPT_DEVICES=0,1,3        the same over the GPUs listed (an index may repeat: rehearsal on one GPU)
+//   HPT_SCENE                bunny | glass | heightfield:<n> instead of the reference's Cornell box
 #include <cstdlib>
 #include <iostream>
 #include <string>
@@ -46,6 +49,17 @@ int main(int argc, char** argv) {
         r.SetMode(mode);
         r.num_threads = num_threads;
         if (const char* d = getenv("HPT_DEVICE")) r.device = atoi(d);
+        if (const char* g = getenv("HPT_GPUS"))
+            for (int k = 0; k < atoi(g); ++k) r.devices.push_back(k);
+        if (const char* l = getenv("HPT_DEVICES")) {
+            r.devices.clear();
+            for (const char* q = l; *q;) {
+                r.devices.push_back(atoi(q));
+                while (*q && *q != ',') ++q;
+                if (*q == ',') ++q;
+            }
+        }
+        if (r.devices.size() > 1) std::cout << "HIP #GPUs: " << r.devices.size() << std::endl;
         if (const char* t = getenv("HPT_TRAVERSAL")) r.traversal = std::string(t) == "culled" ? HPT_TRAVERSAL_CULLED : HPT_TRAVERSAL_REFERENCE;
 
         r.PrepareRender(scene);

@@ -182,6 +182,37 @@ int hpt_host_render(const hpt_host_scene* s, int device, int spp, int max_depth,
     })
 }
 
+int hpt_host_render_devices(const hpt_host_scene* s, const int* devices, int num_devices, int spp, int max_depth, int num_threads,
+                            int mode, int iterative, float* rgb, hpt_stats* stats) {
+    if (!s || !rgb || !devices || num_devices < 1) return fail("null argument");
+    if (mode != 1 && mode != 2) return fail("mode must be 1 (SingleKernel) or 2 (Streamed)");
+    GUARD({
+        Scene sc = s->scene;
+        sc.maxDepth = max_depth;
+        HipRenderer r;
+        r.spp = spp;
+        r.devices.assign(devices, devices + num_devices);
+        r.SetMode((HipRenderMode)mode);
+        r.num_threads = num_threads;
+        r.PrepareRender(sc);
+        if (iterative) {
+            for (int iter = 0; iter < spp; ++iter) r.PathTrace(sc, iter);
+        } else {
+            std::streambuf* old = std::cout.rdbuf(nullptr);
+            try {
+                r.Render(sc);
+            } catch (...) {
+                std::cout.rdbuf(old);
+                throw;
+            }
+            std::cout.rdbuf(old);
+        }
+        if (stats) *stats = r.Stats();
+        r.FinishRender(sc);
+        std::memcpy(rgb, r.framebuffer.data(), r.framebuffer.size() * sizeof(Vec3));
+    })
+}
+
 int hpt_host_render_iterative(const hpt_host_scene* s, int device, int spp, int max_depth, int num_threads, int mode,
                               float* rgb, hpt_stats* stats) {
     if (!s || !rgb) return fail("null argument");

@@ -22,6 +22,18 @@ def sample_range(spp, rank, world_size):
     return begin, base + (1 if rank < extra else 0)
 
 
+def reduce_accum(accum, dist, dst=0):
+    """ONE reduce(SUM) of the int64 accumulators onto ``dst``.  backend nccl (= RCCL): on the GPU
+    tensor, over xGMI.  backend gloo (CPU tests; rehearsals of several ranks on one GPU): through a
+    host copy, the result written back into ``accum`` on every rank (only ``dst`` holds the sum)."""
+    if dist.get_backend() == "nccl" or not accum.is_cuda:
+        dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM)
+    else:
+        host = accum.cpu()
+        dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM)
+        accum.copy_(host)
+
+
 def render_sharded(trace, accum, spp, rank, world_size, dist=None, dst=0):
     """Trace this rank's share of ``spp`` samples and sum all shares onto ``dst``.
 
@@ -36,5 +48,5 @@ def render_sharded(trace, accum, spp, rank, world_size, dist=None, dst=0):
     if count:
         trace(begin, count)
     if dist is not None and world_size > 1:
-        dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM)
+        reduce_accum(accum, dist, dst)
     return begin, count

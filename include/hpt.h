@@ -231,6 +231,27 @@ int hpt_stats_reset(hpt_ctx* ctx);
  * reduce it across GPUs themselves */
 int hpt_accum_buffer(hpt_ctx* ctx, int64_t** accum_dev, size_t* num_elements);
 
+/* cudaDeviceSynchronize of CudaRenderer::Render (gpu_path_tracer/CudaRenderer.cu:63): waits for
+ * everything queued on the context's device.  Call THIS rather than another library's
+ * synchronize: a process can hold more than one HIP runtime (PyTorch wheels bundle their own). */
+int hpt_synchronize(hpt_ctx* ctx);
+
+/* The exact accumulators (int64[3*width*height], 40.24 fixed point) copied to host memory after
+ * waiting for the device; accum_dev = NULL reads the context's own buffer.  No counterpart in the
+ * reference (its framebuffer is float); serves tests and checkpointing a progressive render. */
+int hpt_accum_download(hpt_ctx* ctx, const int64_t* accum_dev, int64_t* accum_host);
+
+/* Multi-GPU accumulation (no counterpart in the reference, which renders on one device,
+ * gpu_path_tracer/CudaRenderer.hpp:18): sums the contexts' own accumulation buffers into the
+ * buffer of ctxs[root].  Contexts on the same device are added there; distinct devices are summed
+ * with ONE RCCL reduce (ncclInt64, ncclSum; RCCL is loaded on first use).  Integer sums are
+ * associative, so the image is bit-identical to a single-GPU render of the same samples.  All
+ * contexts must hold scenes of one resolution.  Waits for the contexts' queued renders and for the
+ * reduce.  The other contexts' buffers are left in an unspecified state (clear them before reuse).
+ * One process drives all devices (one host thread per device for the renders); processes that own
+ * one GPU each reduce hpt_accum_buffer() with their own communicator instead. */
+int hpt_accum_reduce(hpt_ctx* const* ctxs, int n, int root);
+
 /* Host-only (no GPU, no context): the nine per-octant node-array copies that hpt_scene_upload
  * derives for scenes of up to 64 triangles, for inspection and for tests of the claim they rest
  * on (a walk over copy k reaches exactly the leaves whose boxes the ray hits, minus triangles

@@ -59,6 +59,11 @@ int hpt_host_render(const hpt_host_scene* s, int device, int spp, int max_depth,
  * then FinishRender, which downloads the framebuffer once. */
 int hpt_host_render_iterative(const hpt_host_scene* s, int device, int spp, int max_depth, int num_threads, int mode,
                               float* rgb, hpt_stats* stats);
+/* The same with the samples sharded over the GPUs listed (HipRenderer::devices; an index may repeat):
+ * one host thread per entry renders a contiguous sample range, hpt_accum_reduce sums the buffers
+ * onto devices[0].  iterative != 0: through PathTrace, sample iter on entry iter mod num_devices. */
+int hpt_host_render_devices(const hpt_host_scene* s, const int* devices, int num_devices, int spp, int max_depth,
+                            int num_threads, int mode, int iterative, float* rgb, hpt_stats* stats);
 /* Utility::SavePPM (common/Utility.cpp:4-22) */
 int hpt_host_save_ppm(const char* path, const float* rgb, int width, int height);
 /* Utility::SavePFM: linear float RGB as a portable float map (no counterpart in the reference) */

@@ -117,13 +117,7 @@ def test_accumulators_bit_exact_and_split_invariant(hp, oracle, gpu_ctx):
     want, _ = osc.render(RNG_PHILOX, TRIG_PORTABLE, depth, spp, fixed=True)
 
     def download():
-        ptr, n = gpu_ctx.accum_buffer()
-        out = np.zeros(n, np.int64)
-        hip = C.CDLL("libamdhip64.so")
-        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-        assert hip.hipDeviceSynchronize() == 0
-        assert hip.hipMemcpy(out.ctypes.data, ptr, n * 8, 2) == 0
-        return out.reshape(-1, 3)
+        return gpu_ctx.accum_download()
 
     gpu_ctx.accum_clear()
     gpu_ctx.render(1, 256, depth, 0, spp)
