@@ -131,6 +131,9 @@ def _declare(L, H):
     H.hpt_host_last_error.restype = C.c_char_p
     H.hpt_host_scene_cornell.argtypes = [C.c_char_p, i32, i32, i32, C.POINTER(vp)]
     H.hpt_host_scene_builtin.argtypes = [i32, C.c_char_p, i32, i32, i32, C.POINTER(vp)]
+    H.hpt_host_scene_named.argtypes = [C.c_char_p, C.c_char_p, i32, i32, i32, C.POINTER(vp)]
+    H.hpt_host_scene_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, i32]
+    H.hpt_host_scene_add_obj_transformed.argtypes = [vp, C.c_char_p, C.POINTER(hpt_material), vp, vp, vp]
     H.hpt_host_scene_create.argtypes = [i32, i32, vp, C.c_double, i32, C.POINTER(vp)]
     H.hpt_host_scene_add_obj.argtypes = [vp, C.c_char_p, C.POINTER(hpt_material)]
     H.hpt_host_scene_add_triangles.argtypes = [vp, vp, i32, C.POINTER(hpt_material)]
@@ -213,9 +216,30 @@ class Scene:
         s._built = True
         return s
 
-    def Add(self, mesh, material):
-        """mesh: path of an OBJ file, or an array of triangle vertices (n, 3, 3)."""
-        if isinstance(mesh, (str, bytes, os.PathLike)):
+    @staticmethod
+    def CreateNamedScene(name, maxDepth=10, width=0, height=0, models_dir=DEFAULT_MODELS_DIR):
+        """Scene::CreateNamedScene: "cornell" | "bunny" | "glass" | "heightfield:<n>" | "file:<scene file>"."""
+        H = load_libraries()[1]
+        h = C.c_void_p()
+        _ckh(H.hpt_host_scene_named(name.encode(), models_dir.encode(), int(width), int(height), int(maxDepth), C.byref(h)))
+        w, hh = C.c_int(), C.c_int()
+        buf = C.create_string_buffer(256)
+        _ckh(H.hpt_host_scene_info(h, C.byref(w), C.byref(hh), buf, 256))
+        s = Scene(w.value, hh.value, maxDepth=maxDepth, _handle=h)
+        s.name = buf.value.decode()
+        s._built = True
+        return s
+
+    def Add(self, mesh, material, translation=None, rotation=None, scale=None):
+        """mesh: path of an OBJ file (optionally with a Transform: translation, rotation in degrees about
+        x, y, z, scale), or an array of triangle vertices (n, 3, 3)."""
+        if isinstance(mesh, (str, bytes, os.PathLike)) and (translation is not None or rotation is not None or scale is not None):
+            t = np.asarray(translation if translation is not None else (0, 0, 0), np.float32)
+            r = np.asarray(rotation if rotation is not None else (0, 0, 0), np.float32)
+            sc = np.broadcast_to(np.asarray(scale if scale is not None else 1, np.float32), (3,)).copy()
+            _ckh(self._H.hpt_host_scene_add_obj_transformed(self._h, os.fspath(mesh).encode(), C.byref(material), t.ctypes.data,
+                                                            r.ctypes.data, sc.ctypes.data))
+        elif isinstance(mesh, (str, bytes, os.PathLike)):
             _ckh(self._H.hpt_host_scene_add_obj(self._h, os.fspath(mesh).encode(), C.byref(material)))
         else:
             v = np.ascontiguousarray(mesh, np.float32).reshape(-1, 9)

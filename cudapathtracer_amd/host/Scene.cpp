@@ -1,5 +1,7 @@
 #include "Scene.hpp"
 
+#include <random>
+
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -181,6 +183,7 @@ hpt_scene_desc Scene::describe() const {
 // file names of common/Scene.cpp:25-73.
 Scene Scene::CreateBuiltinScene(Scene::BuiltinScene sceneId, int maxDepth) {
     if (sceneId == Scene::BuiltinScene::BunnyInCornell) return CreateBunnyScene(maxDepth);
+    if (sceneId == Scene::BuiltinScene::HeightfieldInCornell) return CreateHeightfieldScene(708, maxDepth);
     if (sceneId != Scene::BuiltinScene::CornellBox && sceneId != Scene::BuiltinScene::GlassCornell)
         throw std::runtime_error("Unsupported sceneId");
     Scene scene(512, 512);
@@ -253,4 +256,119 @@ Scene Scene::CreateBunnyScene(int maxDepth) {
     scene.Add(new MeshTriangle(moved, white));
     scene.buildBVH();
     return scene;
+}
+
+namespace {
+
+// The materials of the reference's Cornell box (common/Scene.cpp:34-53)
+struct CornellMaterials {
+    Material red, green, white, light;
+    CornellMaterials() {
+        red._albedo = Vec3(0.63f, 0.065f, 0.05f);
+        green._albedo = Vec3(0.14f, 0.45f, 0.091f);
+        white._albedo = Vec3(0.725f, 0.71f, 0.68f);
+        light._emission = (8.0f * Vec3(0.747f + 0.058f, 0.747f + 0.258f, 0.747f) + 15.6f * Vec3(0.740f + 0.287f, 0.740f + 0.160f, 0.740f) +
+                           18.4f * Vec3(0.737f + 0.642f, 0.737f + 0.159f, 0.737f));
+    }
+};
+
+void add_cornell_shell(Scene& scene, const CornellMaterials& m) {
+    const char* env = std::getenv("HPT_MODELS_DIR");
+    const std::string root = std::string(env && *env ? env : "models");
+    scene.Add(new MeshTriangle(root + "/cornellbox/floor.obj", m.white));
+    scene.Add(new MeshTriangle(root + "/cornellbox/left.obj", m.red));
+    scene.Add(new MeshTriangle(root + "/cornellbox/right.obj", m.green));
+    scene.Add(new MeshTriangle(root + "/cornellbox/light.obj", m.light));
+}
+
+// MT19937 as numpy.random.RandomState(seed) runs it: init_genrand seeding (what std::mt19937(seed)
+// does) and 53-bit doubles from two outputs, (a >> 5) * 2^26 + (b >> 6) over 2^53.
+struct NumpyRandom {
+    std::mt19937 gen;
+    explicit NumpyRandom(uint32_t seed) : gen(seed) {}
+    double rand() {
+        const uint32_t a = (uint32_t)gen() >> 5, b = (uint32_t)gen() >> 6;
+        return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+    }
+};
+
+// numpy.linspace(lo, hi, num): i * step + lo with step = (hi - lo) / (num - 1), the last element hi
+std::vector<double> linspace(double lo, double hi, int num) {
+    std::vector<double> v((size_t)num);
+    const double step = (hi - lo) / (double)(num - 1);
+    for (int i = 0; i < num; ++i) v[(size_t)i] = (double)i * step + lo;
+    v[(size_t)num - 1] = hi;
+    return v;
+}
+
+}  // namespace
+
+// n x n cells over the floor rectangle [30, 526] x [30, 529] (x, z), heights 40 + 60 * smooth noise
+// (a 9 x 9 random grid, bilinearly interpolated) + a little per-vertex jitter, two upward-facing
+// triangles per cell.  Every operation in double, in the order cudapathtracer_amd/scenes.py
+// (heightfield_triangles, seed 1234) performs it, then rounded to float once: the vertices are
+// the same bit for bit.
+Scene Scene::CreateHeightfieldScene(int n, int maxDepth) {
+    Scene scene(512, 512);
+    scene.name = "Heightfield " + std::to_string(n);
+    scene.maxDepth = maxDepth;
+    scene.camPos = Vec3(278, 273, -800);
+    const CornellMaterials mats;
+    add_cornell_shell(scene, mats);
+    scene.Add(new MeshTriangle(HeightfieldVertices(n), mats.white));
+    scene.buildBVH();
+    return scene;
+}
+
+std::vector<Vec3> Scene::HeightfieldVertices(int n) {
+    if (n < 1 || n > 4096) throw std::runtime_error("height field: n must be in [1, 4096]");
+    const double base = 40.0, amplitude = 60.0;
+    NumpyRandom rs(1234u);
+    double coarse[9][9];
+    for (auto& row : coarse)
+        for (double& c : row) c = rs.rand();
+    const int m = n + 1;
+    const std::vector<double> u = linspace(0.0, 8.0, m);
+    std::vector<int> i0((size_t)m);
+    std::vector<double> f((size_t)m);
+    for (int i = 0; i < m; ++i) {
+        i0[(size_t)i] = std::min((int)u[(size_t)i], 7);
+        f[(size_t)i] = u[(size_t)i] - (double)i0[(size_t)i];
+    }
+    std::vector<double> h((size_t)m * m);
+    for (int i = 0; i < m; ++i)
+        for (int j = 0; j < m; ++j) {
+            const int a = i0[(size_t)i], b = i0[(size_t)j];
+            const double fi = f[(size_t)i], fj = f[(size_t)j];
+            double rows = coarse[a][b] * ((1 - fi) * (1 - fj));
+            rows = rows + coarse[a + 1][b] * (fi * (1 - fj));
+            rows = rows + coarse[a][b + 1] * ((1 - fi) * fj);
+            rows = rows + coarse[a + 1][b + 1] * (fi * fj);
+            h[(size_t)i * m + j] = rows;
+        }
+    const double jitter = amplitude / (double)n;
+    for (size_t k = 0; k < h.size(); ++k) h[k] = (base + amplitude * h[k]) + jitter * rs.rand();
+    const std::vector<double> x = linspace(30.0, 526.0, m), z = linspace(30.0, 529.0, m);
+    auto P = [&](int i, int j) { return Vec3((float)x[(size_t)i], (float)h[(size_t)i * m + j], (float)z[(size_t)j]); };
+    std::vector<Vec3> fv;
+    fv.reserve((size_t)n * n * 6);
+    // counter-clockwise seen from above: first all (a, d, c) triangles, then all (a, c, b)
+    for (int pass = 0; pass < 2; ++pass)
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) {
+                const Vec3 a = P(i, j), b = P(i + 1, j), c = P(i + 1, j + 1), d = P(i, j + 1);
+                fv.push_back(a);
+                fv.push_back(pass == 0 ? d : c);
+                fv.push_back(pass == 0 ? c : b);
+            }
+    return fv;
+}
+
+Scene Scene::CreateNamedScene(const std::string& name, int maxDepth) {
+    if (name.empty() || name == "cornell") return CreateBuiltinScene(CornellBox, maxDepth);
+    if (name == "bunny") return CreateBuiltinScene(BunnyInCornell, maxDepth);
+    if (name == "glass") return CreateBuiltinScene(GlassCornell, maxDepth);
+    if (name.rfind("heightfield:", 0) == 0) return CreateHeightfieldScene(std::atoi(name.c_str() + 12), maxDepth);
+    if (name.rfind("file:", 0) == 0) return LoadSceneFile(name.substr(5), maxDepth);
+    throw std::runtime_error("unknown scene '" + name + "' (cornell | bunny | glass | heightfield:<n> | file:<path>)");
 }

@@ -68,11 +68,22 @@ public:
         // The Cornell box with the short box made of the glass that common/Scene.cpp:45-47
         // parametrises (roughness 0.2, ior 1.5) but leaves Lambertian: Material::Type::Glass.
         GlassCornell,
+        // Cornell walls + light over an n x n displaced height field (2 n^2 triangles; n = 708 gives
+        // 1.0 M): the BVH-fetch stress scene.  Created with CreateHeightfieldScene(n, maxDepth); the same
+        // scene is defined, vertex for vertex, in cudapathtracer_amd/scenes.py (heightfield_in_cornell).
+        HeightfieldInCornell,
     };
     // OBJ files are opened as "models/<dir>/<name>.obj" relative to the
     // current directory, or under $HPT_MODELS_DIR when that is set.
     static Scene CreateBuiltinScene(BuiltinScene sceneId, int maxDepth);
     static Scene CreateBunnyScene(int maxDepth);
+    static Scene CreateHeightfieldScene(int n, int maxDepth);
+    static std::vector<Vec3> HeightfieldVertices(int n);  // 3 vertices per triangle, 2 n^2 triangles
+    // A scene description file (the "self-defined material description file" of the reference's
+    // roadmap, README.md:62; format: host/SceneFile.cpp).  Paths in it are relative to the file.
+    static Scene LoadSceneFile(const std::string& path, int maxDepth);
+    // "cornell" | "bunny" | "glass" | "heightfield:<n>" | "file:<path>" (what HPT_SCENE accepts)
+    static Scene CreateNamedScene(const std::string& name, int maxDepth);
 
     // tan(fov/2) exactly as the host renderer of the reference computes it
     // (common/Renderer.cpp:11,20)

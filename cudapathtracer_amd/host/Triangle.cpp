@@ -1,6 +1,7 @@
 #include "Triangle.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <limits>
@@ -60,6 +61,73 @@ std::vector<Vec3> read_obj(const std::string& filename) {
 }  // namespace
 
 MeshTriangle::MeshTriangle(const std::string& filename, const Material& mt) { build(read_obj(filename), mt); }
+
+MeshTriangle::MeshTriangle(const std::string& filename, const Material& mt, const Transform& transform) {
+    std::vector<Vec3> fv = read_obj(filename);
+    if (!transform.identity()) {
+        float m[4][4];
+        transform.matrix(m);
+        for (Vec3& v : fv) v = transform.apply(m, v);
+    }
+    build(fv, mt);
+}
+
+bool Transform::identity() const {
+    return translation.x == 0.f && translation.y == 0.f && translation.z == 0.f && rotation.x == 0.f && rotation.y == 0.f &&
+           rotation.z == 0.f && scale.x == 1.f && scale.y == 1.f && scale.z == 1.f;
+}
+
+namespace {
+void mat_identity(float m[4][4]) {
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 4; ++r) m[c][r] = c == r ? 1.f : 0.f;
+}
+// out = a * b (column-major: out[c] = a[0]*b[c][0] + a[1]*b[c][1] + a[2]*b[c][2] + a[3]*b[c][3], summed left to right)
+void mat_mul(const float a[4][4], const float b[4][4], float out[4][4]) {
+    float t[4][4];
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 4; ++r) t[c][r] = ((a[0][r] * b[c][0] + a[1][r] * b[c][1]) + a[2][r] * b[c][2]) + a[3][r] * b[c][3];
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 4; ++r) out[c][r] = t[c][r];
+}
+// rotation by `deg` degrees about coordinate axis `axis` (0 x, 1 y, 2 z), angle = deg * Pi / 180.f
+void mat_rotation(float deg, int axis, float m[4][4]) {
+    const float pi = 3.1415926535897932384626422832795028841971f;
+    const float a = deg * pi / 180.f;
+    const float c = std::cos(a), s = std::sin(a);
+    mat_identity(m);
+    const int u = (axis + 1) % 3, v = (axis + 2) % 3;
+    m[u][u] = c;
+    m[u][v] = s;
+    m[v][u] = -s;
+    m[v][v] = c;
+}
+}  // namespace
+
+void Transform::matrix(float m[4][4]) const {
+    float t[4][4], r[4][4], rx[4][4], ry[4][4], rz[4][4], sc[4][4], tr[4][4];
+    mat_identity(t);
+    t[3][0] = translation.x;
+    t[3][1] = translation.y;
+    t[3][2] = translation.z;
+    mat_rotation(rotation.x, 0, rx);
+    mat_rotation(rotation.y, 1, ry);
+    mat_rotation(rotation.z, 2, rz);
+    mat_mul(rx, ry, r);
+    mat_mul(r, rz, r);
+    mat_identity(sc);
+    sc[0][0] = scale.x;
+    sc[1][1] = scale.y;
+    sc[2][2] = scale.z;
+    mat_mul(t, r, tr);
+    mat_mul(tr, sc, m);
+}
+
+Vec3 Transform::apply(const float m[4][4], Vec3 v) const {
+    float out[3];
+    for (int r = 0; r < 3; ++r) out[r] = (m[0][r] * v.x + m[1][r] * v.y) + (m[2][r] * v.z + m[3][r]);
+    return Vec3(out[0], out[1], out[2]);
+}
 
 MeshTriangle::MeshTriangle(const std::vector<Vec3>& face_vertices, const Material& mt) {
     if (face_vertices.empty() || face_vertices.size() % 3 != 0) throw std::runtime_error("MeshTriangle: vertex count must be a positive multiple of 3");

@@ -35,12 +35,26 @@ public:
     Bounds3 getBounds() const override { return Union(Bounds3(v0, v1), v2); }
 };
 
+// Translation, rotation (degrees about x, then y, then z) and scale of a mesh, composed as
+// Math::buildTransformationMatrix does (common/MathUtils.hpp:109-116): M = T * Rx * Ry * Rz * S.
+// The reference declares that helper and never calls it (a MeshTriangle is the OBJ's vertices
+// verbatim, common/Triangle.cpp:28-53); here a mesh can be given one.  Applied to every vertex in
+// float, column by column as the reference's vector library multiplies mat4 * vec4:
+// (m0 * x + m1 * y) + (m2 * z + m3).  Parity unpinned: nothing in the reference exercises it.
+struct Transform {
+    Vec3 translation = Vec3(0.f), rotation = Vec3(0.f), scale = Vec3(1.f);
+    bool identity() const;
+    void matrix(float m[4][4]) const;  // m[column][row]
+    Vec3 apply(const float m[4][4], Vec3 v) const;
+};
+
 class MeshTriangle : public Object {
 public:
     // Wavefront OBJ with `v` and triangular `f` records, one mesh per file
     // (what common/Triangle.cpp:5-61 accepts through the vendored loader).
     // Throws std::runtime_error if the file cannot be read or a face is not a triangle.
     MeshTriangle(const std::string& filename, const Material& mt);
+    MeshTriangle(const std::string& filename, const Material& mt, const Transform& transform);
     // triangle soup: 3 vertices per face
     MeshTriangle(const std::vector<Vec3>& face_vertices, const Material& mt);
 

@@ -11,7 +11,7 @@
 //   HPT_DEVICE               GPU index (default 0)
 //   HPT_GPUS=N               shard the samples over GPUs 0..N-1 (one RCCL reduce sums the accumulators)
 //   HPT_DEVICES=0,1,3        the same over the GPUs listed (an index may repeat: rehearsal on one GPU)
-//   HPT_SCENE                bunny | glass | heightfield:<n> instead of the reference's Cornell box
+//   HPT_SCENE                bunny | glass | heightfield:<n> | file:<scene file> instead of the reference's Cornell box
 #include <cstdlib>
 #include <iostream>
 #include <string>
@@ -31,10 +31,9 @@ int main(int argc, char** argv) {
     if (argc > 4) mode = (HipRenderMode)atoi(argv[4]);
 
     try {
-        // HPT_SCENE=bunny / glass renders one of the other built-in scenes instead of the reference's only one
+        // HPT_SCENE=bunny / glass / heightfield:<n> / file:<path> renders another scene than the reference's only one
         const char* which = getenv("HPT_SCENE");
-        const std::string name = which ? which : "";
-        Scene scene = Scene::CreateBuiltinScene(name == "bunny" ? Scene::BunnyInCornell : name == "glass" ? Scene::GlassCornell : Scene::CornellBox, maxDepth);
+        Scene scene = Scene::CreateNamedScene(which ? which : "cornell", maxDepth);
         if (const char* w = getenv("HPT_WIDTH")) scene.width = atoi(w);
         if (const char* h = getenv("HPT_HEIGHT")) scene.height = atoi(h);
 

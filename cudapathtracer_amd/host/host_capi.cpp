@@ -75,6 +75,41 @@ int hpt_host_scene_builtin(int scene_id, const char* models_dir, int width, int 
     })
 }
 
+int hpt_host_scene_named(const char* name, const char* models_dir, int width, int height, int max_depth, hpt_host_scene** out) {
+    if (!out || !name) return fail("null argument");
+    *out = nullptr;
+    GUARD({
+        if (models_dir) setenv("HPT_MODELS_DIR", models_dir, 1);
+        Scene sc = Scene::CreateNamedScene(name, max_depth);
+        if (width > 0) sc.width = width;
+        if (height > 0) sc.height = height;
+        *out = new hpt_host_scene(sc);
+    })
+}
+
+int hpt_host_scene_info(const hpt_host_scene* s, int* width, int* height, char* name, int name_cap) {
+    if (!s) return fail("scene is null");
+    if (width) *width = s->scene.width;
+    if (height) *height = s->scene.height;
+    if (name && name_cap > 0) {
+        std::strncpy(name, s->scene.name.c_str(), (size_t)name_cap - 1);
+        name[name_cap - 1] = '\0';
+    }
+    return 0;
+}
+
+int hpt_host_scene_add_obj_transformed(hpt_host_scene* s, const char* obj_path, const hpt_material* material, const float translation[3],
+                                       const float rotation_deg[3], const float scale[3]) {
+    if (!s || !obj_path || !material || !translation || !rotation_deg || !scale) return fail("null argument");
+    GUARD({
+        Transform t;
+        t.translation = Vec3(translation[0], translation[1], translation[2]);
+        t.rotation = Vec3(rotation_deg[0], rotation_deg[1], rotation_deg[2]);
+        t.scale = Vec3(scale[0], scale[1], scale[2]);
+        s->scene.Add(new MeshTriangle(std::string(obj_path), to_material(material), t));
+    })
+}
+
 int hpt_host_scene_create(int width, int height, const float cam_pos[3], double fov_deg, int max_depth, hpt_host_scene** out) {
     if (!out || !cam_pos) return fail("null argument");
     *out = nullptr;

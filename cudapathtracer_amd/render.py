@@ -22,16 +22,7 @@ import time
 
 
 def build_scene(hp, name, width, height, depth):
-    from . import scenes
-    if name == "cornell":
-        return hp.Scene.CreateBuiltinScene(hp.Scene.CornellBox, depth, width, height)
-    if name == "bunny":
-        return hp.Scene.CreateBuiltinScene(hp.Scene.BunnyInCornell, depth, width, height)
-    if name == "glass":
-        return hp.Scene.CreateBuiltinScene(hp.Scene.GlassCornell, depth, width, height)
-    if name.startswith("heightfield:"):
-        return scenes.heightfield_in_cornell(int(name.split(":")[1]), width, height, depth)
-    raise SystemExit("unknown --scene " + name)
+    return hp.Scene.CreateNamedScene(name, depth, width, height)
 
 
 def parse(argv):
@@ -41,7 +32,7 @@ def parse(argv):
     ap.add_argument("threads", nargs="?", type=int, default=256)
     ap.add_argument("mode", nargs="?", type=int, default=1)
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--scene", default="cornell", help="cornell | bunny | glass | heightfield:<n>")
+    ap.add_argument("--scene", default="cornell", help="cornell | bunny | glass | heightfield:<n> | file:<scene file>")
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--out", default=None, help="PPM file (default out/gpu/<scene name>.ppm, like the reference)")

@@ -29,6 +29,15 @@ int hpt_host_scene_cornell(const char* models_dir, int width, int height, int ma
  * reference sets that material's glass parameters, common/Scene.cpp:45-47, but not its type). */
 int hpt_host_scene_builtin(int scene_id, const char* models_dir, int width, int height, int max_depth, hpt_host_scene** out);
 /* empty scene: Scene(w, h) + camera (common/Scene.hpp:23-45) */
+/* Scene::CreateNamedScene: "cornell" | "bunny" | "glass" | "heightfield:<n>" | "file:<scene file>"
+ * (what the CLI's HPT_SCENE accepts; scene file format: host/SceneFile.cpp).  width/height 0 keep
+ * the scene's own resolution. */
+int hpt_host_scene_named(const char* name, const char* models_dir, int width, int height, int max_depth, hpt_host_scene** out);
+int hpt_host_scene_info(const hpt_host_scene* s, int* width, int* height, char* name, int name_cap);
+/* MeshTriangle with a Transform: translation, rotation in degrees about x, y, z, scale, composed as
+ * Math::buildTransformationMatrix (common/MathUtils.hpp:109-116), which the reference never calls. */
+int hpt_host_scene_add_obj_transformed(hpt_host_scene* s, const char* obj_path, const hpt_material* material, const float translation[3],
+                                       const float rotation_deg[3], const float scale[3]);
 int hpt_host_scene_create(int width, int height, const float cam_pos[3], double fov_deg, int max_depth,
                           hpt_host_scene** out);
 /* Scene::Add(new MeshTriangle(...)) (common/Scene.hpp:47-56, common/Triangle.cpp:5-61) */

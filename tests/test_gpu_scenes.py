@@ -3,6 +3,8 @@
 height fields up to ~1.0 M triangles (BVH of 2.0 M nodes).  Same bar as
 test_gpu_parity.py: ids, t bits, ray counters and images bit-exact against the
 CPU oracle built from the same triangle arrays."""
+import os
+
 import numpy as np
 import pytest
 
@@ -322,3 +324,53 @@ def test_full_size_properties(hp, gpu_ctx):
     assert np.isfinite(img).all() and (img >= 0).all()
     assert img[:8].max() == 0.0                 # the rows above the box see no geometry: no background radiance
     assert 0.3 < img[400:600, 400:600].mean() < 1.5
+
+
+def test_full_size_heightfield_properties(hp, gpu_ctx):
+    """The last benchmark configuration's scene and resolution (1.0 M triangles, 2048 x 2048, depth 20)
+    through the C++ host's own scene builder: the single-kernel and the streamed mode (wave scheduler)
+    give the same accumulators, a split sample range sums to the whole, every path is accounted for,
+    and hpt_render_static-sized pieces are not needed (one call traces 4.2 M paths per sample)."""
+    import torch
+    w = h = 2048
+    depth, spp = 20, 2
+    sc = hp.Scene.CreateNamedScene("heightfield:708", depth, w, h)
+    gpu_ctx.upload(sc)
+    assert gpu_ctx.stats()["variant"] == 5
+    st = torch.cuda.current_stream()
+    a = torch.zeros(3 * w * h, dtype=torch.int64, device="cuda:0")
+    b = torch.zeros_like(a)
+    gpu_ctx.stats_reset()
+    gpu_ctx.render(2, 256, depth, 0, spp, accum=a, stream=st)
+    gpu_ctx.synchronize()
+    s1 = gpu_ctx.stats()
+    gpu_ctx.stats_reset()
+    gpu_ctx.render(1, 256, depth, 0, 1, accum=b, stream=st)
+    gpu_ctx.render(2, 128, depth, 1, 1, accum=b, stream=st)
+    gpu_ctx.synchronize()
+    s2 = gpu_ctx.stats()
+    assert torch.equal(a, b)
+    assert s1["paths"] == s2["paths"] == w * h * spp
+    assert (s1["closest_queries"], s1["shadow_queries"]) == (s2["closest_queries"], s2["shadow_queries"])
+    assert 9.5 < (s1["closest_queries"] + s1["shadow_queries"]) / s1["paths"] < 11.5
+    img = gpu_ctx.resolve(spp, accum=a).reshape(h, w, 3)
+    assert np.isfinite(img).all() and (img >= 0).all() and img[:16].max() == 0.0
+    assert 0.2 < img[1200:1500, 800:1200].mean() < 2.0   # the lit height field fills the lower half of the picture
+
+
+def test_cli_renders_the_large_scene_configurations(tmp_path):
+    """gpu_path_tracer on the bunny (streamed mode) and on the 1.0 M-triangle height field, as the
+    benchmark configurations name them, at a reduced sample count."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    (tmp_path / "out" / "gpu").mkdir(parents=True)
+    for scene, res, name in (("bunny", "1024", "Bunny"), ("heightfield:708", "2048", "Heightfield 708")):
+        env = dict(os.environ, HPT_MODELS_DIR=os.path.join(root, "models"), HPT_SCENE=scene, HPT_WIDTH=res, HPT_HEIGHT=res)
+        r = subprocess.run([os.path.join(root, "build", "gpu_path_tracer"), "4", "20", "256", "2"], cwd=str(tmp_path), env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=110)
+        assert r.returncode == 0, r.stdout
+        assert "Resolution: %sx%s" % (res, res) in r.stdout and "HIP Mode: Streamed" in r.stdout
+        data = (tmp_path / "out" / "gpu" / (name + ".ppm")).read_bytes()
+        assert data.startswith(b"P6\n%s %s\n255\n" % (res.encode(), res.encode())) and len(data) > 3 * int(res) ** 2
+        body = np.frombuffer(data[-3 * int(res) ** 2:], np.uint8)
+        assert body.max() == 255 and 20 < body.mean() < 200

@@ -376,3 +376,100 @@ def test_host_bvh_equals_the_reference_on_large_scenes(hp, tag):
     assert [bvh_hash(sc.bvh_dump(m)) for m in range(-1, len(parts))] == [int(v) for v in g["bvh_hashes"]]
     f = sc.flat_arrays()
     assert np.array_equal(bits(np.array([f["sum_light_area"], f["sum_light_power"]], np.float32)), bits(g["light_totals"]))
+
+
+def test_builtin_heightfield_scene_equals_the_python_definition(hp):
+    """Scene::CreateHeightfieldScene (C++: MT19937 as numpy runs it, the bilinear noise in double) and
+    scenes.heightfield_in_cornell (numpy) flatten to the same arrays, bit for bit -- the 1.0 M-triangle
+    scene of the last benchmark configuration included."""
+    from cudapathtracer_amd import scenes
+    for n in (5, 64, 708):
+        a = hp.Scene.CreateNamedScene("heightfield:%d" % n, 7, 64, 48)
+        assert a.name == "Heightfield %d" % n
+        a, b = a.flat_arrays(), scenes.heightfield_in_cornell(n, 64, 48, 7).flat_arrays()
+        assert a["tris"].shape == (12 + 2 * n * n, 16)
+        for k in ("nodes", "tris", "tri_v12", "node_area", "prim_of_tri"):
+            assert np.array_equal(np.asarray(a[k]).view(np.uint32), np.asarray(b[k]).view(np.uint32)), (n, k)
+        assert a["cam_scale"] == b["cam_scale"] and a["lights"] == b["lights"]
+    with pytest.raises(hp.HptError):
+        hp.Scene.CreateNamedScene("heightfield:0")
+    with pytest.raises(hp.HptError):
+        hp.Scene.CreateNamedScene("teapot")
+
+
+def test_mesh_transform(hp, tmp_path):
+    """A MeshTriangle with a Transform (translation, rotation, scale composed as the reference's unused
+    Math::buildTransformationMatrix, common/MathUtils.hpp:109-116) against the same matrix in numpy."""
+    mat = hp.Material(albedo=(0.5, 0.5, 0.5))
+    obj = os.path.join(ROOT, "models", "cornellbox", "shortbox.obj")
+    t, r, s = (10.0, -20.0, 30.0), (30.0, 45.0, 60.0), (2.0, 0.5, 1.5)
+    sc = hp.Scene(32, 32)
+    sc.Add(obj, mat, translation=t, rotation=r, scale=s)
+    sc.buildBVH()
+    got = sc.flat_arrays()
+    plain = hp.Scene(32, 32)
+    plain.Add(obj, mat)
+    plain.buildBVH()
+    ref = plain.flat_arrays()
+    ax, ay, az = np.radians(r)
+    rx = np.array([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]])
+    ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]])
+    rz = np.array([[np.cos(az), -np.sin(az), 0], [np.sin(az), np.cos(az), 0], [0, 0, 1]])
+    m = rx @ ry @ rz @ np.diag(s)
+    # triangles are stored in leaf order, which the transform changes: compare them by primitive id
+    def v0_by_prim(f):
+        out = np.zeros((len(f["tris"]), 3))
+        out[f["prim_of_tri"]] = f["tris"][:, 0:3]
+        return out
+    want = v0_by_prim(ref) @ m.T + np.asarray(t)
+    assert np.abs(v0_by_prim(got) - want).max() < 2e-3
+    # identity transform == no transform, bit for bit
+    same = hp.Scene(32, 32)
+    same.Add(obj, mat, translation=(0, 0, 0), rotation=(0, 0, 0), scale=1.0)
+    same.buildBVH()
+    assert np.array_equal(same.flat_arrays()["tris"].view(np.uint32), ref["tris"].view(np.uint32))
+
+
+def test_scene_file(hp, tmp_path):
+    """A scene description file that spells out the reference's Cornell box gives the built-in scene bit
+    for bit; transforms, the height field statement and the error messages."""
+    models = os.path.join(ROOT, "models", "cornellbox")
+    e = [8.0 * np.float32(0.747 + 0.058) + 15.6 * np.float32(0.740 + 0.287) + 18.4 * np.float32(0.737 + 0.642)]
+    text = """# the reference's Cornell box (common/Scene.cpp:25-73)
+name Cornell Box
+resolution 64 48
+camera 278 273 -800 fov 40
+material white lambert albedo 0.725 0.71 0.68
+material red lambert albedo 0.63 0.065 0.05
+material green lambert albedo 0.14 0.45 0.091
+material box lambert roughness 0.2 ior 1.5
+material metal metal albedo 0.7 0.5 0.2 metallic 1 roughness 0.005
+material light lambert emission %s
+mesh {m}/floor.obj white
+mesh {m}/shortbox.obj box
+mesh {m}/tallbox.obj metal
+mesh {m}/left.obj red
+mesh {m}/right.obj green
+mesh {m}/light.obj light
+""".replace("{m}", models)
+    from cudapathtracer_amd import scenes
+    emission = " ".join("%.9g" % v for v in scenes.light_emission())
+    path = tmp_path / "cornell.scene"
+    path.write_text(text % emission)
+    a = hp.Scene.CreateNamedScene("file:" + str(path), 7)
+    assert (a.width, a.height, a.name) == (64, 48, "Cornell Box")
+    b = hp.Scene.CreateBuiltinScene(hp.Scene.CornellBox, 7, 64, 48)
+    fa, fb = a.flat_arrays(), b.flat_arrays()
+    raw = lambda v: np.atleast_1d(np.asarray(v)).tobytes()
+    for k in fa:
+        assert raw(fa[k]) == raw(fb[k]), k
+    # relative paths, a transformed mesh, the height field statement
+    (tmp_path / "box.obj").write_text(open(os.path.join(models, "shortbox.obj")).read())
+    (tmp_path / "b.scene").write_text("material w lambert\nmaterial g glass roughness 0.1 ior 1.4\nmesh box.obj g translate 0 100 0 scale 2\nheightfield 4 w\n")
+    c = hp.Scene.CreateNamedScene("file:" + str(tmp_path / "b.scene"), 3).flat_arrays()
+    assert c["tris"].shape[0] == 10 + 32 and c["materials"][0][0] == 2
+    for bad, msg in (("mesh nothing.obj w\n", "has not been defined"), ("material g glass\n", "ior"), ("colour red\n", "unknown statement"),
+                     ("material w lambert\n", "defines no mesh"), ("material w lambert\nmesh missing.obj w\n", "cannot open")):
+        (tmp_path / "bad.scene").write_text(bad)
+        with pytest.raises(hp.HptError, match=msg):
+            hp.Scene.CreateNamedScene("file:" + str(tmp_path / "bad.scene"), 3)
