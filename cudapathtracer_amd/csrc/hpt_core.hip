@@ -43,6 +43,21 @@ constexpr uint32_t kLdsLimit = 32u * 1024u;
 constexpr uint32_t kLdsLimitTiny = 44u * 1024u;  // nine node copies of a 64-triangle scene (127 nodes) + its triangles
 constexpr uint32_t kMaxLdsPerBlock = 160u * 1024u;  // LDS of a gfx950 compute unit; one workgroup may use all of it
 constexpr uint32_t kMaxStackDepth = 40;  // per-lane stack entries (4 B each in LDS); median-split trees need ~log2(triangles)
+// Traversal variants that run under the wave scheduler by default (bit = variant number), per mode:
+// the two-child-record walks through L1/L2 (5) and their culled form (7).  Measured on MI355X: the
+// scheduler gains 1.6x (bunny) and 1.55x / 2.2x (1.0 M-triangle height field, streamed / single
+// kernel) there, where a walk is tens of dependent fetches long and most lanes are in the "step"
+// state most of the time.  It LOSES where the walk is short and the shading weighs as much as the
+// walk (Cornell box, LDS marking variants: 9.9 vs 29.2 Grays/s; LDS pair records: 7.0 vs 8.8):
+// 64 lanes spread over four states leave every kind of round a third full, and a scheduling
+// decision costs as much as a box step.  Those keep the lock-step kernels.
+#ifndef HPT_MEGA_SCHEDULER_DEFAULT
+#define HPT_MEGA_SCHEDULER_DEFAULT 0xA0u
+#endif
+#ifndef HPT_WF_SCHEDULER_DEFAULT
+#define HPT_WF_SCHEDULER_DEFAULT 0xA0u
+#endif
+constexpr uint32_t kMegaSchedulerVariants = HPT_MEGA_SCHEDULER_DEFAULT, kWfSchedulerVariants = HPT_WF_SCHEDULER_DEFAULT;
 constexpr int kStatClosest = 0, kStatShadow = 1, kStatPaths = 2, kStatBox = 3, kStatTri = 4, kNumStats = 6;
 
 thread_local std::string g_last_error;
@@ -539,10 +554,168 @@ k_wf_bounces(DevScene S, int max_depth, uint32_t seg, WfQueue q0, WfQueue q1, co
 #endif
 enum { kLaneIdle = 0, kLaneWalk = 1, kLaneShadeA = 2, kLaneShadeB = 3 };
 
-// All bounces of a segment's paths, like k_wf_bounces, for the pair variants.
+// The scheduler loop of one wave.  `Policy` is the mode's side of it:
+//   uint32_t refillable(m_idle, m_busy)   how many of the idle lanes could be given a path now (wave-uniform)
+//   void refill(idle, p, got)             collective: hand paths to idle lanes (got = this lane received one)
+//   void count_closest() / count_shadow() ray counters
+//   void finish(p)                        per lane: the path has ended, add its radiance to the picture
+//   bool next_bounce(keep, p)             collective: the bounce is shaded and the path goes on (keep); returns
+//                                         whether THIS lane carries the path into its next bounce itself
+template <int kScene, bool kGlass, class Policy>
+__device__ __forceinline__ void schedule_wave(const DevScene& S, const float4* lds, TriQueue tq, int max_depth, Policy& pol COUNT_ARG) {
+    using Trav = Traversal<kScene>;
+    typename Trav::State W;
+    Trav::init(W);
+    int st = kLaneIdle;
+    Path p;
+    int hit_tri = -1;
+    double hit_t = 0.0;
+    LightSample ls{};
+    bool lit = false;  // kLaneShadeB: a shadow ray was traced (its answer is in W)
+    for (;;) {
+        const bool walking = st == kLaneWalk;
+        const bool can_step = walking && Trav::can_step(W);
+        const bool wants_test = walking && Trav::wants_test(W);
+        const uint32_t c_step = (uint32_t)__popcll(__ballot(can_step));
+        const uint32_t c_tri = (uint32_t)__popcll(__ballot(wants_test));
+        const uint32_t c_a = (uint32_t)__popcll(__ballot(st == kLaneShadeA));
+        const uint32_t c_b = (uint32_t)__popcll(__ballot(st == kLaneShadeB));
+        const unsigned long long m_idle = __ballot(st == kLaneIdle);
+        const uint32_t c_idle = m_idle ? pol.refillable(m_idle, __ballot(st != kLaneIdle)) : 0u;
+        // what to run: the first kind of round that reaches its threshold, else the most wanted
+        int what;  // 0 refill, 1 step, 2 triangles, 3 shade A, 4 shade B
+        if (c_idle >= HPT_SM_T_REFILL) what = 0;
+        else if (c_step >= HPT_SM_T_STEP) what = 1;
+        else if (c_tri >= HPT_SM_T_TRI) what = 2;
+        else if (c_b >= HPT_SM_T_SHADE) what = 4;
+        else if (c_a >= HPT_SM_T_SHADE) what = 3;
+        else {
+            uint32_t best = c_step;
+            what = 1;
+            if (c_tri > best) { best = c_tri; what = 2; }
+            if (c_b > best) { best = c_b; what = 4; }
+            if (c_a > best) { best = c_a; what = 3; }
+            if (c_idle > best) { best = c_idle; what = 0; }
+            if (best == 0u) break;  // every lane idle and nothing left to hand out
+        }
+        if (what == 0) {
+            bool got = false;
+            pol.refill(st == kLaneIdle, p, got);
+            if (got) {
+                pol.count_closest();
+                Trav::begin(S, lds, W, p.o, p.d, false, 0.f COUNT_PASS);
+                st = kLaneWalk;
+            }
+        } else if (what == 1) {
+            // rounds of box steps while enough lanes take part
+            do {
+                if (st == kLaneWalk && Trav::can_step(W)) Trav::step(S, lds, tq, W COUNT_PASS);
+            } while ((uint32_t)__popcll(__ballot(st == kLaneWalk && Trav::can_step(W))) >= HPT_SM_T_STEP);
+        } else if (what == 2) {
+            // rounds of triangle tests: every lane that has a triangle to test takes part (also lanes
+            // that could still step: the round costs the same), until too few lanes are blocked
+            do {
+                if (st == kLaneWalk && Trav::may_test(W)) Trav::test_one(S, lds, tq, W COUNT_PASS);
+            } while ((uint32_t)__popcll(__ballot(st == kLaneWalk && Trav::wants_test(W))) >= HPT_SM_T_TRI);
+        } else if (what == 3) {
+            if (st == kLaneShadeA) {
+                f3 so, wi;
+                float tmax;
+                const int rc = shade_a(S, p, hit_tri, hit_t, so, wi, tmax, ls);
+                if (rc == kShadeMiss) {
+                    pol.finish(p);
+                    st = kLaneIdle;
+                } else if (rc == kShadeShadowRay) {
+                    pol.count_shadow();
+                    Trav::begin(S, lds, W, so, wi, true, tmax COUNT_PASS);
+                    lit = true;
+                    st = kLaneWalk;
+                } else {
+                    lit = false;
+                    st = kLaneShadeB;
+                }
+            }
+        } else {
+            bool keep = false;
+            const bool shading = st == kLaneShadeB;
+            if (shading) {
+                shade_b<kGlass>(S, p, hit_tri, hit_t, lit && W.best < 0, W.d, ls);
+                keep = p.depth < max_depth;
+                if (!keep) pol.finish(p);
+                st = kLaneIdle;
+            }
+            if (pol.next_bounce(keep, p)) {  // this lane traces the path's next bounce itself
+                pol.count_closest();
+                Trav::begin(S, lds, W, p.o, p.d, false, 0.f COUNT_PASS);
+                st = kLaneWalk;
+            }
+        }
+        // walks that have just ended: the marking variants' back-face filter, then the lane goes to the shading
+        if (st == kLaneWalk) {
+            Trav::settle(S, lds, W COUNT_PASS);
+            if (Trav::done(W)) {
+                if (W.shadow) {
+                    st = kLaneShadeB;
+                } else {
+                    hit_tri = W.best;
+                    hit_t = W.best_t;
+                    st = kLaneShadeA;
+                }
+            }
+        }
+    }
+}
+
+// ---- streamed mode under the scheduler ----
+struct WfPolicy {
+    const WfQueue& q_in;
+    const WfQueue& q_out;
+    size_t seg_base;
+    uint32_t count;                 // records of this bounce in the segment
+    uint32_t* s_next;               // LDS: next record nobody has taken
+    uint32_t* s_out;                // LDS: survivors stored so far
+    int64_t* accum;
+    uint32_t lane;
+    bool more = true;               // wave-uniform: the segment may still hold records nobody has taken
+    uint32_t n_closest = 0, n_shadow = 0;
+    __device__ __forceinline__ uint32_t refillable(unsigned long long m_idle, unsigned long long) const { return more ? (uint32_t)__popcll(m_idle) : 0u; }
+    __device__ __forceinline__ void refill(bool idle, Path& p, bool& got) {
+        const unsigned long long m = __ballot(idle);
+        const uint32_t n = (uint32_t)__popcll(m);
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(s_next, n);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (base + n >= count) more = false;
+        if (idle) {
+            const uint32_t i = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (i < count) {
+                const WfRecord cur = wf_fetch(q_in, seg_base, i, count);
+                wf_unpack(cur, p);
+                got = p.pixel != 0xFFFFFFFFu;  // not a dead record
+            }
+        }
+    }
+    __device__ __forceinline__ void count_closest() { ++n_closest; }
+    __device__ __forceinline__ void count_shadow() { ++n_shadow; }
+    __device__ __forceinline__ void finish(const Path& p) { accumulate_pixel(accum, p.pixel, p.rad); }
+    // survivors are compacted into the other queue: ballot, prefix count, one LDS atomic per wave
+    __device__ __forceinline__ bool next_bounce(bool keep, const Path& p) {
+        const unsigned long long mask = __ballot(keep);
+        if (mask) {
+            const int leader = __ffsll((long long)mask) - 1;
+            uint32_t slot = 0;
+            if ((int)lane == leader) slot = atomicAdd(s_out, (uint32_t)__popcll(mask));
+            slot = __shfl(slot, leader);
+            if (keep) wf_store(q_out, seg_base + slot + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)), p);
+        }
+        return false;
+    }
+};
+
 #ifndef HPT_SM_WAVES
 #define HPT_SM_WAVES 1
 #endif
+// All bounces of a segment's paths, like k_wf_bounces, under the wave scheduler.
 template <int kScene, bool kGlass>
 __global__ void __launch_bounds__(256, HPT_SM_WAVES)
 k_wf_bounces_sm(DevScene S, int max_depth, uint32_t seg, WfQueue q0, WfQueue q1, const uint32_t* __restrict__ live,
@@ -555,136 +728,165 @@ k_wf_bounces_sm(DevScene S, int max_depth, uint32_t seg, WfQueue q0, WfQueue q1,
     const uint32_t lane = threadIdx.x & 63u;
     const size_t seg_base = (size_t)blockIdx.x * seg;
     const TriQueue tq = make_tri_queue<kScene>(reinterpret_cast<uint32_t*>(lds + S.lds_float4s));
-    const float4* N = kScene == kScenePairLds ? lds : S.pairs;
-    const float4* T = kScene == kScenePairLds ? lds + 4u * S.num_pairs : S.tris;
     uint32_t n_closest = 0, n_shadow = 0;
     COUNT_DECL;
     for (int bounce = 0; bounce < max_depth && count; ++bounce) {
-        const WfQueue& q_in = (bounce & 1) ? q1 : q0;
-        const WfQueue& q_out = (bounce & 1) ? q0 : q1;
         if (threadIdx.x == 0) {
             s_out = 0;
             s_next = 0;
         }
         __syncthreads();  // also: the records the previous bounce stored are visible to the whole workgroup
-        int st = kLaneIdle;
-        bool more = true;  // wave-uniform: the segment may still hold records nobody has taken
-        Path p;
-        Walk W;
-        W.cur = -1;
-        W.cnt = 0u;
-        int hit_tri = -1;
-        double hit_t = 0.0;
-        LightSample ls{};
-        bool lit = false;  // kLaneShadeB: a shadow ray was traced (its answer is in W)
-        for (;;) {
-            const bool walking = st == kLaneWalk;
-            const bool can_step = walking && walk_can_step<kScene>(W);
-            const bool wants_tri = walking && !can_step && W.cnt > 0u;
-            const uint32_t c_step = (uint32_t)__popcll(__ballot(can_step));
-            const uint32_t c_tri = (uint32_t)__popcll(__ballot(wants_tri));
-            const uint32_t c_a = (uint32_t)__popcll(__ballot(st == kLaneShadeA));
-            const uint32_t c_b = (uint32_t)__popcll(__ballot(st == kLaneShadeB));
-            const unsigned long long m_idle = __ballot(st == kLaneIdle);
-            const uint32_t c_idle = more ? (uint32_t)__popcll(m_idle) : 0u;
-            // what to run: the first kind of round that reaches its threshold, else the most wanted
-            int what;  // 0 refill, 1 step, 2 triangles, 3 shade A, 4 shade B
-            if (c_idle >= HPT_SM_T_REFILL) what = 0;
-            else if (c_step >= HPT_SM_T_STEP) what = 1;
-            else if (c_tri >= HPT_SM_T_TRI) what = 2;
-            else if (c_b >= HPT_SM_T_SHADE) what = 4;
-            else if (c_a >= HPT_SM_T_SHADE) what = 3;
-            else {
-                uint32_t best = c_step;
-                what = 1;
-                if (c_tri > best) { best = c_tri; what = 2; }
-                if (c_b > best) { best = c_b; what = 4; }
-                if (c_a > best) { best = c_a; what = 3; }
-                if (c_idle > best) { best = c_idle; what = 0; }
-                if (best == 0u) break;  // every lane idle and the segment empty
-            }
-            if (what == 0) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&s_next, c_idle);
-                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                if (base + c_idle >= count) more = false;
-                if (st == kLaneIdle) {
-                    const uint32_t i = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m_idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_idle, 0u));
-                    if (i < count) {
-                        const WfRecord cur = wf_fetch(q_in, seg_base, i, count);
-                        wf_unpack(cur, p);
-                        if (p.pixel != 0xFFFFFFFFu) {  // not a dead record
-                            ++n_closest;
-                            walk_begin<kScene>(S, W, p.o, p.d, false, 0.f COUNT_PASS);
-                            st = walk_done(W) ? kLaneShadeA : kLaneWalk;
-                            hit_tri = -1;
-                            hit_t = (double)kInfinity;
-                        }
-                    }
-                }
-            } else if (what == 1) {
-                // rounds of box steps while enough lanes take part
-                do {
-                    if (st == kLaneWalk && walk_can_step<kScene>(W)) walk_step<kScene>(S, N, tq, W COUNT_PASS);
-                } while ((uint32_t)__popcll(__ballot(st == kLaneWalk && walk_can_step<kScene>(W))) >= HPT_SM_T_STEP);
-            } else if (what == 2) {
-                // rounds of triangle tests: every lane with a queued triangle takes part (the lanes that
-                // could still step as well: the round costs the same), until too few lanes are blocked
-                do {
-                    if (st == kLaneWalk && W.cnt > 0u) walk_test_one<kScene>(S, T, tq, W COUNT_PASS);
-                } while ((uint32_t)__popcll(__ballot(st == kLaneWalk && !walk_can_step<kScene>(W) && W.cnt > 0u)) >= HPT_SM_T_TRI);
-            } else if (what == 3) {
-                if (st == kLaneShadeA) {
-                    f3 so, wi;
-                    float tmax;
-                    const int rc = shade_a(S, p, hit_tri, hit_t, so, wi, tmax, ls);
-                    if (rc == kShadeMiss) {
-                        accumulate_pixel(accum, p.pixel, p.rad);
-                        st = kLaneIdle;
-                    } else if (rc == kShadeShadowRay) {
-                        ++n_shadow;
-                        walk_begin<kScene>(S, W, so, wi, true, tmax COUNT_PASS);
-                        lit = true;
-                        st = walk_done(W) ? kLaneShadeB : kLaneWalk;
-                    } else {
-                        lit = false;
-                        st = kLaneShadeB;
-                    }
-                }
-            } else {
-                bool keep = false;
-                if (st == kLaneShadeB) {
-                    shade_b<kGlass>(S, p, hit_tri, hit_t, lit && W.best < 0, W.d, ls);
-                    keep = p.depth < max_depth;
-                    if (!keep) accumulate_pixel(accum, p.pixel, p.rad);
-                    st = kLaneIdle;
-                }
-                const unsigned long long mask = __ballot(keep);
-                if (mask) {
-                    const int leader = __ffsll((long long)mask) - 1;
-                    uint32_t slot = 0;
-                    if ((int)lane == leader) slot = atomicAdd(&s_out, (uint32_t)__popcll(mask));
-                    slot = __shfl(slot, leader);
-                    if (keep) wf_store(q_out, seg_base + slot + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)), p);
-                }
-            }
-            // walks that have just ended hand their lane to the shading
-            if (st == kLaneWalk && walk_done(W)) {
-                if (W.shadow) {
-                    st = kLaneShadeB;
-                } else {
-                    hit_tri = W.best;
-                    hit_t = W.best_t;
-                    st = kLaneShadeA;
-                }
-            }
-        }
+        WfPolicy pol{(bounce & 1) ? q1 : q0, (bounce & 1) ? q0 : q1, seg_base, count, &s_next, &s_out, accum, lane};
+        schedule_wave<kScene, kGlass>(S, lds, tq, max_depth, pol COUNT_PASS);
+        n_closest += pol.n_closest;
+        n_shadow += pol.n_shadow;
         __syncthreads();
         count = s_out;  // survivors = the next bounce's paths
         __syncthreads();
     }
     stat_add(stats + kStatClosest, n_closest);
     stat_add(stats + kStatShadow, n_shadow);
+    COUNT_FLUSH(stats);
+}
+
+// ---- single-kernel mode under the scheduler ----
+// The work pool of k_render_mega (units of (8x8 pixel tile, s_chunk samples) drawn from a global counter,
+// two units in flight per wave, one 64-pixel accumulator in LDS per unit) as the scheduler's source of paths.
+struct MegaPolicy {
+    const DevScene& S;
+    uint32_t s_begin_all, s_count_all, s_chunk, n_units;
+    unsigned long long* out;
+    unsigned long long* stats;
+    uint32_t* unit_counter;
+    unsigned long long* tile_acc;
+    uint32_t lane, wave_lanes, W, H, tiles_x, n_tiles;
+    // wave-uniform unit state: the unit whose pool is being handed out, and the one before it
+    uint32_t cur_x0 = 0, cur_y0 = 0, cur_vw = 1, cur_nv = 0, cur_s0 = 0, cur_total = 0, cur_next = 0;
+    uint32_t old_x0 = 0, old_y0 = 0, old_vw = 1, old_nv = 0;
+    bool cur_open = false, old_open = false, queue_empty = false;
+    uint32_t gen = 0;  // accumulator of `cur`; `old` uses the other one
+    // per lane
+    uint32_t n_closest = 0, n_shadow = 0, n_paths_wave = 0, slot = 0, lane_gen = 0;
+
+    __device__ __forceinline__ void flush(unsigned long long* acc, uint32_t x0, uint32_t y0, uint32_t vw, uint32_t nv) {
+        for (uint32_t j = lane; j < nv; j += wave_lanes) {
+            const unsigned long long pix = (unsigned long long)(y0 + j / vw) * W + x0 + j % vw;
+            for (uint32_t c = 0; c < 3u; ++c) {
+                const unsigned long long v = acc[3u * j + c];
+                if (v) atomicAdd(out + 3ull * pix + c, v);
+                acc[3u * j + c] = 0ull;
+            }
+        }
+    }
+    __device__ __forceinline__ bool pool_has_items() const { return cur_open && cur_next < cur_total; }
+    // idle lanes can be served from the open pool, or from the next unit once the unit before the current
+    // one has no path in flight any more (its accumulator is needed for the new unit)
+    __device__ __forceinline__ uint32_t refillable(unsigned long long m_idle, unsigned long long m_busy) {
+        if (pool_has_items()) return (uint32_t)__popcll(m_idle);
+        if (queue_empty) return 0u;
+        const bool old_busy = old_open && __ballot(lane_gen != gen) & m_busy;
+        return old_busy ? 0u : (uint32_t)__popcll(m_idle);
+    }
+    __device__ __forceinline__ void refill(bool idle, Path& p, bool& got) {
+        const unsigned long long need = __ballot(idle);
+        if (!pool_has_items() && !queue_empty) {
+            // pool exhausted (and `old` has drained, see refillable): retire `old`, open the next unit
+            if (old_open) {
+                flush(tile_acc + (gen ^ 1u) * 192u, old_x0, old_y0, old_vw, old_nv);
+                old_open = false;
+            }
+            uint32_t u = 0;
+            if (lane == 0) u = atomicAdd(unit_counter, 1u);
+            u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u);
+            if (u < n_units) {
+                // the per-lane ray counters are emptied here: between two openings a lane traces at most
+                // 64 * s_chunk * max_depth rays (< 2^32 for the sizes the host allows)
+                stat_add(stats + kStatClosest, n_closest);
+                stat_add(stats + kStatShadow, n_shadow);
+                n_closest = n_shadow = 0;
+                old_x0 = cur_x0;
+                old_y0 = cur_y0;
+                old_vw = cur_vw;
+                old_nv = cur_nv;
+                old_open = cur_open;
+                gen ^= 1u;
+                const uint32_t tile = u % n_tiles, chunk = u / n_tiles;
+                cur_x0 = (tile % tiles_x) * 8u;
+                cur_y0 = (tile / tiles_x) * 8u;
+                cur_vw = min(8u, W - cur_x0);
+                cur_nv = cur_vw * min(8u, H - cur_y0);  // pixels of an edge tile
+                cur_s0 = s_begin_all + chunk * s_chunk;
+                cur_total = cur_nv * min(s_chunk, s_count_all - chunk * s_chunk);
+                cur_next = 0;
+                cur_open = true;
+                n_paths_wave += cur_total;  // every item of a pool is traced
+            } else {
+                queue_empty = true;
+            }
+        }
+        if (pool_has_items()) {
+            const uint32_t k = cur_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+            cur_next = min(cur_total, cur_next + (uint32_t)__popcll(need));
+            if (idle && k < cur_total) {
+                uint32_t px, py, smp;
+                if (cur_nv == 64u) {  // full tile (wave-uniform): no integer divisions
+                    slot = k & 63u;
+                    smp = k >> 6;
+                    px = slot & 7u;
+                    py = slot >> 3;
+                } else {
+                    slot = k % cur_nv;
+                    smp = k / cur_nv;
+                    px = slot % cur_vw;
+                    py = slot / cur_vw;
+                }
+                generate_camera_path(S, (cur_y0 + py) * W + cur_x0 + px, cur_s0 + smp, p);
+                lane_gen = gen;
+                got = true;
+            }
+        }
+    }
+    __device__ __forceinline__ void count_closest() { ++n_closest; }
+    __device__ __forceinline__ void count_shadow() { ++n_shadow; }
+    __device__ __forceinline__ void finish(const Path& p) {
+        unsigned long long* acc = tile_acc + lane_gen * 192u + 3u * slot;
+        atomicAdd(acc + 0u, (unsigned long long)radiance_to_fixed(p.rad.x));
+        atomicAdd(acc + 1u, (unsigned long long)radiance_to_fixed(p.rad.y));
+        atomicAdd(acc + 2u, (unsigned long long)radiance_to_fixed(p.rad.z));
+    }
+    __device__ __forceinline__ bool next_bounce(bool keep, const Path&) const { return keep; }  // the lane keeps its path
+    __device__ __forceinline__ void close() {
+        if (old_open) flush(tile_acc + (gen ^ 1u) * 192u, old_x0, old_y0, old_vw, old_nv);
+        if (cur_open) flush(tile_acc + gen * 192u, cur_x0, cur_y0, cur_vw, cur_nv);
+        stat_add(stats + kStatClosest, n_closest);
+        stat_add(stats + kStatShadow, n_shadow);
+        stat_add(stats + kStatPaths, lane == 0 ? n_paths_wave : 0u);
+    }
+};
+
+#ifndef HPT_MEGA_SM_WAVES
+#define HPT_MEGA_SM_WAVES 4
+#endif
+template <int kScene, bool kGlass, int kMaxBlock>
+__global__ void __launch_bounds__(kMaxBlock, (kMaxBlock == 256 ? HPT_MEGA_SM_WAVES : 1))
+k_render_mega_sm(DevScene S, int max_depth, uint32_t s_begin_all, uint32_t s_count_all, uint32_t s_chunk, uint32_t n_units,
+                 int64_t* __restrict__ accum, unsigned long long* __restrict__ stats, uint32_t* __restrict__ unit_counter) {
+    extern __shared__ float4 lds[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t waves_per_block = (blockDim.x + 63u) >> 6;
+    const uint32_t wave_lanes = min(64u, blockDim.x - wave * 64u);  // the last wave of an odd-sized block is partial
+    // two accumulators (unit generations 0 / 1) of 64 pixels x RGB per wave
+    unsigned long long* tile_acc = reinterpret_cast<unsigned long long*>(lds + S.lds_float4s) + wave * 384u;
+    for (uint32_t i = lane; i < 384u; i += wave_lanes) tile_acc[i] = 0ull;
+    const TriQueue tq = make_tri_queue<kScene>(reinterpret_cast<uint32_t*>(lds + S.lds_float4s) + waves_per_block * 768u);
+    stage_scene<kScene>(S, lds);
+    const uint32_t W = (uint32_t)S.width, H = (uint32_t)S.height;
+    const uint32_t tiles_x = (W + 7u) >> 3;
+    MegaPolicy pol{S, s_begin_all, s_count_all, s_chunk, n_units, reinterpret_cast<unsigned long long*>(accum), stats, unit_counter,
+                   tile_acc, lane, wave_lanes, W, H, tiles_x, tiles_x * ((H + 7u) >> 3)};
+    COUNT_DECL;
+    schedule_wave<kScene, kGlass>(S, lds, tq, max_depth, pol COUNT_PASS);
+    pol.close();
     COUNT_FLUSH(stats);
 }
 
@@ -701,6 +903,11 @@ __global__ void k_resolve(const int64_t* __restrict__ accum, size_t n, double de
 }
 
 }  // namespace
+
+// variants that have a resumable Traversal<> and therefore run under the wave scheduler
+constexpr bool has_scheduler(int variant) {
+    return variant == kSceneTiny32 || variant == kSceneTiny64 || variant == kScenePair || variant == kScenePairLds || variant == kScenePairCull;
+}
 
 // run CALL with kS bound to the scene's traversal variant as a compile-time constant
 #define HPT_DISPATCH_SCENE(variant, ...)                                                 \
@@ -1289,15 +1496,26 @@ int render_launch(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sam
         if (lds_mega > kMaxLdsPerBlock)
             return fail(HPT_ERR_INVALID_ARGUMENT, "a workgroup of %d lanes needs %u bytes of LDS for this scene (limit %u): use a smaller block", block, lds_mega, kMaxLdsPerBlock);
         int per_cu = 0;
+        // HPT_SCHEDULER=0 (or, for the streamed mode, HPT_WF_SCHEDULER=0): the plain loops, for A/B runs.
+        // HPT_SCHEDULER_VARIANTS: bit mask of the traversal variants that run under the scheduler in this mode.
+        const char* sched_env = getenv("HPT_SCHEDULER");
+        const char* sched_mask = getenv("HPT_MEGA_SCHEDULER_VARIANTS");
+        const uint32_t mega_mask = sched_mask ? (uint32_t)strtoul(sched_mask, nullptr, 0) : kMegaSchedulerVariants;
+        const bool scheduler = has_scheduler(S.variant) && !(sched_env && atoi(sched_env) == 0) && ((mega_mask >> S.variant) & 1u);
+#define HPT_MEGA_KERNEL(kS, kG, kB) (scheduler ? reinterpret_cast<const void*>(&k_render_mega_sm<has_scheduler(kS) ? kS : kScenePair, kG, kB>) \
+                                               : reinterpret_cast<const void*>(&k_render_mega<kS, kG, kB>))
         HPT_DISPATCH_RENDER(S.variant, ctx->has_glass, {
             if (block <= 256) {
-                if (lds_mega > 48u * 1024u) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render_mega<kS, kG, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mega));
-                HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_mega<kS, kG, 256>, block, lds_mega));
+                if (lds_mega > 48u * 1024u) HIP_TRY(hipFuncSetAttribute(HPT_MEGA_KERNEL(kS, kG, 256), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mega));
+                if (scheduler) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_mega_sm<has_scheduler(kS) ? kS : kScenePair, kG, 256>, block, lds_mega));
+                else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_mega<kS, kG, 256>, block, lds_mega));
             } else {
-                if (lds_mega > 48u * 1024u) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render_mega<kS, kG, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mega));
-                HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_mega<kS, kG, 1024>, block, lds_mega));
+                if (lds_mega > 48u * 1024u) HIP_TRY(hipFuncSetAttribute(HPT_MEGA_KERNEL(kS, kG, 1024), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mega));
+                if (scheduler) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_mega_sm<has_scheduler(kS) ? kS : kScenePair, kG, 1024>, block, lds_mega));
+                else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_mega<kS, kG, 1024>, block, lds_mega));
             }
         })
+#undef HPT_MEGA_KERNEL
         if (per_cu < 1) return fail(HPT_ERR_INVALID_ARGUMENT, "a workgroup of %d lanes with %u bytes of LDS does not fit a compute unit", block, lds_mega);
         const uint32_t resident = (uint32_t)per_cu * (uint32_t)ctx->num_cus;
         for (uint32_t s = sample_begin; s < sample_begin + sample_count;) {
@@ -1306,8 +1524,14 @@ int render_launch(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sam
             const uint32_t blocks = std::min(resident, (units + waves_per_block - 1u) / waves_per_block);
             HIP_TRY(hipMemsetAsync(unit_counter, 0, sizeof(uint32_t), stream));
             HPT_DISPATCH_RENDER(S.variant, ctx->has_glass, {
-                if (block <= 256) hipLaunchKernelGGL((k_render_mega<kS, kG, 256>), dim3(blocks), dim3(block), lds_mega, stream, S, max_depth, s, n, chunk, units, accum, ctx->d_stats, unit_counter);
-                else hipLaunchKernelGGL((k_render_mega<kS, kG, 1024>), dim3(blocks), dim3(block), lds_mega, stream, S, max_depth, s, n, chunk, units, accum, ctx->d_stats, unit_counter);
+                constexpr int kT = has_scheduler(kS) ? kS : kScenePair;  // (never launched for variants without a Traversal<>)
+                if (scheduler) {
+                    if (block <= 256) hipLaunchKernelGGL((k_render_mega_sm<kT, kG, 256>), dim3(blocks), dim3(block), lds_mega, stream, S, max_depth, s, n, chunk, units, accum, ctx->d_stats, unit_counter);
+                    else hipLaunchKernelGGL((k_render_mega_sm<kT, kG, 1024>), dim3(blocks), dim3(block), lds_mega, stream, S, max_depth, s, n, chunk, units, accum, ctx->d_stats, unit_counter);
+                } else {
+                    if (block <= 256) hipLaunchKernelGGL((k_render_mega<kS, kG, 256>), dim3(blocks), dim3(block), lds_mega, stream, S, max_depth, s, n, chunk, units, accum, ctx->d_stats, unit_counter);
+                    else hipLaunchKernelGGL((k_render_mega<kS, kG, 1024>), dim3(blocks), dim3(block), lds_mega, stream, S, max_depth, s, n, chunk, units, accum, ctx->d_stats, unit_counter);
+                }
             })
             HIP_TRY(hipGetLastError());
             ++launches;
@@ -1322,11 +1546,13 @@ int render_launch(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sam
         // one queue segment per workgroup; exactly the workgroups that are resident at once
         int per_cu = 0;
         // scenes read through two-child records run the wave scheduler (HPT_WF_SCHEDULER=0: the plain loop, for A/B runs)
-        const bool pair_variant = S.variant == kScenePair || S.variant == kScenePairLds || S.variant == kScenePairCull;
-        const char* sched_env = getenv("HPT_WF_SCHEDULER");
-        const bool scheduler = pair_variant && !(sched_env && atoi(sched_env) == 0);
+        const char* sched_env = getenv("HPT_SCHEDULER");
+        const char* sched_env2 = getenv("HPT_WF_SCHEDULER");
+        const char* sched_mask = getenv("HPT_WF_SCHEDULER_VARIANTS");
+        const uint32_t wf_mask = sched_mask ? (uint32_t)strtoul(sched_mask, nullptr, 0) : kWfSchedulerVariants;
+        const bool scheduler = has_scheduler(S.variant) && !(sched_env && atoi(sched_env) == 0) && !(sched_env2 && atoi(sched_env2) == 0) && ((wf_mask >> S.variant) & 1u);
         HPT_DISPATCH_RENDER(S.variant, ctx->has_glass, {
-            if constexpr (kS == kScenePair || kS == kScenePairLds || kS == kScenePairCull) {
+            if constexpr (has_scheduler(kS)) {
                 if (scheduler) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_bounces_sm<kS, kG>, wblock, lds_bytes(S, wblock)));
                 else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_bounces<kS, kG>, wblock, lds_bytes(S, wblock)));
             } else {
@@ -1360,7 +1586,7 @@ int render_launch(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sam
             hipLaunchKernelGGL(k_wf_generate, dim3(segments), dim3(gblock), 0, stream, S, sample_begin, first, count, (uint32_t)lanes, seg, q[0], live, ctx->d_stats);
             HIP_TRY(hipGetLastError());
             HPT_DISPATCH_RENDER(S.variant, ctx->has_glass, {
-                if constexpr (kS == kScenePair || kS == kScenePairLds || kS == kScenePairCull) {
+                if constexpr (has_scheduler(kS)) {
                     if (scheduler) hipLaunchKernelGGL((k_wf_bounces_sm<kS, kG>), dim3(segments), dim3(wblock), lds_bytes(S, wblock), stream, S, max_depth, seg, q[0], q[1], live, accum, ctx->d_stats);
                     else hipLaunchKernelGGL((k_wf_bounces<kS, kG>), dim3(segments), dim3(wblock), lds_bytes(S, wblock), stream, S, max_depth, seg, q[0], q[1], live, accum, ctx->d_stats);
                 } else {

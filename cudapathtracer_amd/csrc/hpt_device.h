@@ -886,6 +886,170 @@ HD void walk_test_one(const DevScene& S, const float4* __restrict__ T, TriQueue 
     }
 }
 
+// ---- resumable walk of the marking variants ---------------------------------
+// The box walk over the ray's octant copy (one node per step), the back-face filter when the walk
+// ends, then one triangle test per round in ascending index (so the strict `<` of the closest-hit
+// update keeps the reference's tie order).  Same tests as trace<kSceneTiny32/64>.
+template <bool kMask32>
+struct MarkWalk {
+    using mask_t = typename std::conditional<kMask32, uint32_t, unsigned long long>::type;
+    f3 o, d, inv;
+    uint32_t at, stop;  // LDS byte addresses of the next node and of the end of the copy
+    mask_t pending;     // marked triangles; after the filter: triangles still to be tested
+    int best;
+    double best_t;
+    float tmax;
+    bool finite, shadow, filtered;
+};
+
+// One interface over the resumable walks, so that the wave scheduler is written once:
+//   begin      start a closest-hit or any-hit query
+//   can_step   the lane has a box step to make          step      make it
+//   wants_test the lane cannot step, triangles wait      test_one  test one of them
+//   may_test   the lane has a triangle it could test now (a superset of wants_test)
+//   settle     bookkeeping after a round of steps (the marking variants' back-face filter)
+//   done       the query has its answer in best / best_t
+template <int kScene>
+struct Traversal;
+
+template <int kScene>
+struct PairTraversal {
+    using State = Walk;
+    HD static void init(State& W) {
+        W.cur = -1;
+        W.cnt = 0u;
+    }
+    HD static const float4* records(const DevScene& S, const float4* lds) { return kScene == kScenePairLds ? lds : S.pairs; }
+    HD static const float4* triangles(const DevScene& S, const float4* lds) { return kScene == kScenePairLds ? lds + 4u * S.num_pairs : S.tris; }
+    HD static void begin(const DevScene& S, const float4* lds, State& W, f3 o, f3 d, bool shadow, float tmax COUNT_ARG) {
+        walk_begin<kScene>(S, W, o, d, shadow, tmax COUNT_PASS);
+    }
+    HD static bool can_step(const State& W) { return walk_can_step<kScene>(W); }
+    HD static bool wants_test(const State& W) { return !walk_can_step<kScene>(W) && W.cnt > 0u; }
+    HD static bool may_test(const State& W) { return W.cnt > 0u; }
+    HD static bool done(const State& W) { return walk_done(W); }
+    HD static void step(const DevScene& S, const float4* lds, TriQueue tq, State& W COUNT_ARG) { walk_step<kScene>(S, records(S, lds), tq, W COUNT_PASS); }
+    HD static void test_one(const DevScene& S, const float4* lds, TriQueue tq, State& W COUNT_ARG) {
+        walk_test_one<kScene>(S, triangles(S, lds), tq, W COUNT_PASS);
+    }
+    HD static void settle(const DevScene&, const float4*, State& COUNT_ARG) {}
+};
+template <> struct Traversal<kScenePair> : PairTraversal<kScenePair> {};
+template <> struct Traversal<kScenePairLds> : PairTraversal<kScenePairLds> {};
+template <> struct Traversal<kScenePairCull> : PairTraversal<kScenePairCull> {};
+
+template <int kScene>
+struct MarkTraversal {
+    static constexpr bool kMask32 = (kScene == kSceneTiny32);
+    using State = MarkWalk<kMask32>;
+    using mask_t = typename State::mask_t;
+    HD static void init(State& W) {
+        W.at = W.stop = 0u;
+        W.pending = 0;
+        W.filtered = true;
+    }
+    HD static const float4* triangles(const DevScene& S, const float4* lds) { return lds + 18u * S.num_nodes; }
+    HD static void begin(const DevScene& S, const float4* lds, State& W, f3 o, f3 d, bool shadow, float tmax COUNT_ARG) {
+        W.o = o;
+        W.d = d;
+        W.inv = mk(rcp_rn(d.x), rcp_rn(d.y), rcp_rn(d.z));  // == float(1. / double(d)), Ray.hpp:21
+        const float kInf = __builtin_inff();
+        W.finite = fabsf(W.inv.x) < kInf && fabsf(W.inv.y) < kInf && fabsf(W.inv.z) < kInf;
+        W.shadow = shadow;
+        W.tmax = tmax;
+        W.best = -1;
+        W.best_t = (double)kInfinity;
+        W.pending = 0;
+        W.filtered = false;
+        const uint32_t nbase = lds_address(lds), copy_bytes = S.num_nodes * 32u;
+        const uint32_t* table = reinterpret_cast<const uint32_t*>(triangles(S, lds) + 4u * S.num_tris);
+        if (W.finite) {
+            const uint32_t oct = (d.x < 0 ? 1u : 0u) | (d.y < 0 ? 2u : 0u) | (d.z < 0 ? 4u : 0u);
+            W.at = nbase + oct * copy_bytes;
+            W.stop = W.at + table[oct] * 32u;
+        } else {  // a direction component is 0 (or denormal): the whole tree, the reference's NaN-aware test
+            W.at = nbase + 8u * copy_bytes;
+            W.stop = W.at + copy_bytes;
+        }
+    }
+    HD static bool can_step(const State& W) { return W.at < W.stop; }
+    HD static bool wants_test(const State& W) { return W.at >= W.stop && W.pending != 0; }
+    HD static bool may_test(const State& W) { return W.at >= W.stop && W.filtered && W.pending != 0; }
+    HD static bool done(const State& W) { return W.at >= W.stop && W.filtered && W.pending == 0; }
+    HD static void step(const DevScene& S, const float4* lds, TriQueue, State& W COUNT_ARG) {
+        COUNT_BOX(1);
+        const float4 nr = lds_read(W.at), fr = lds_read(W.at + 16u);
+        bool hit;
+        if (W.finite) {
+            const float tnear = fmaxf(fmaxf((nr.x - W.o.x) * W.inv.x, (nr.y - W.o.y) * W.inv.y), (nr.z - W.o.z) * W.inv.z);
+            const float tfar = fminf(fminf((fr.x - W.o.x) * W.inv.x, (fr.y - W.o.y) * W.inv.y), (fr.z - W.o.z) * W.inv.z);
+            hit = tnear <= tfar;
+        } else {
+            hit = box_hit(nr, fr, W.o, W.inv, W.d.x < 0, W.d.y < 0, W.d.z < 0);
+        }
+        if constexpr (kMask32) {
+            W.pending |= hit ? __float_as_uint(fr.w) : 0u;
+        } else {
+            const int tri = __float_as_int(fr.w);
+            if (hit && tri >= 0) W.pending |= (mask_t)1 << tri;
+        }
+        W.at = hit ? W.at + 32u : __float_as_uint(nr.w);
+    }
+    // the walk has ended: drop the marked triangles that face away from the ray (Triangle.hpp:168-169);
+    // the octant decides most of them, the rest are tested here
+    HD static void settle(const DevScene& S, const float4* lds, State& W COUNT_ARG) {
+        if (W.filtered || W.at < W.stop) return;
+        W.filtered = true;
+        const float4* T = triangles(S, lds);
+        const uint32_t* table = reinterpret_cast<const uint32_t*>(T + 4u * S.num_tris);
+        mask_t undecided = W.pending;
+        if (W.finite) {
+            const uint32_t oct = (W.d.x < 0 ? 1u : 0u) | (W.d.y < 0 ? 2u : 0u) | (W.d.z < 0 ? 4u : 0u);
+            if constexpr (kMask32) undecided &= table[16u + 2u * oct];
+            else undecided &= ((mask_t)table[16u + 2u * oct] | ((mask_t)table[17u + 2u * oct] << 32));
+        }
+        if constexpr (kMask32) {
+            for (uint32_t m = undecided; m;) {
+                const int tri = __ffs((int)m) - 1;
+                const float4 nr = T[4 * tri + 3];
+                const uint32_t group = __float_as_uint(nr.w);  // the triangles with this normal: one test settles them all
+                COUNT_TRI(dot(W.d, xyz(nr)) > 0 ? 1 : 0);
+                if (dot(W.d, xyz(nr)) > 0) W.pending &= ~group;
+                m &= ~group;
+            }
+        } else {
+            for (mask_t m = undecided; m;) {
+                const int tri = __ffsll((long long)m) - 1;
+                const mask_t rest = m & (m - 1);
+                COUNT_TRI(dot(W.d, xyz(T[4 * tri + 3])) > 0 ? 1 : 0);
+                if (dot(W.d, xyz(T[4 * tri + 3])) > 0) W.pending ^= m ^ rest;
+                m = rest;
+            }
+        }
+    }
+    HD static void test_one(const DevScene& S, const float4* lds, TriQueue, State& W COUNT_ARG) {
+        const float4* T = triangles(S, lds);
+        const int tri = kMask32 ? __ffs((int)W.pending) - 1 : __ffsll((long long)W.pending) - 1;
+        W.pending &= W.pending - 1;
+        double t;
+        COUNT_TRI(1);
+        if (tri_hit<true>(T, tri, W.o, W.d, t)) {
+            if (W.shadow) {
+                if (t < (double)W.tmax - (double)kEpsilon4) {
+                    W.best = tri;
+                    W.best_t = t;
+                    W.pending = 0;
+                }
+            } else if (t < W.best_t) {
+                W.best = tri;
+                W.best_t = t;
+            }
+        }
+    }
+};
+template <> struct Traversal<kSceneTiny32> : MarkTraversal<kSceneTiny32> {};
+template <> struct Traversal<kSceneTiny64> : MarkTraversal<kSceneTiny64> {};
+
 // -------------------------------------------------------------- shading -----
 // common/MathUtils.hpp:124-222
 HD f3 local_to_world(f3 local_dir, f3 normal) {

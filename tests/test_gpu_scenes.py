@@ -374,3 +374,36 @@ def test_cli_renders_the_large_scene_configurations(tmp_path):
         assert data.startswith(b"P6\n%s %s\n255\n" % (res.encode(), res.encode())) and len(data) > 3 * int(res) ** 2
         body = np.frombuffer(data[-3 * int(res) ** 2:], np.uint8)
         assert body.max() == 255 and 20 < body.mean() < 200
+
+
+@pytest.mark.parametrize("name", ["cornell", "heightfield4", "heightfield8", "bunny"])
+@pytest.mark.parametrize("scheduler", ["all", "off"])
+def test_wave_scheduler_and_lockstep_kernels_agree(hp, oracle, gpu_ctx, monkeypatch, name, scheduler):
+    """Both kernel families on every traversal variant that has both: the wave scheduler (default for
+    the two-child-record walks through L1/L2, forced here for the LDS variants too) and the lock-step
+    loops (default for the LDS variants, forced here for the large scenes) -- images and ray counters
+    equal the oracle's bit for bit in both modes."""
+    from cudapathtracer_amd import scenes
+    if name == "cornell":
+        parts = scenes.glass_cornell_parts(glass=scenes.WHITE)
+    else:
+        parts = scenes.bunny_in_cornell_parts() if name == "bunny" else scenes.heightfield_in_cornell_parts(int(name[11:]))
+    w, h, depth, spp = 52, 36, 7, 3
+    sc = scenes._assemble(parts, w, h, depth)
+    osc = _oracle_scene(oracle, parts, w, h)
+    want_acc, ost = osc.render(RNG_PHILOX, TRIG_PORTABLE, depth, spp, fixed=True)
+    if scheduler == "all":
+        monkeypatch.setenv("HPT_MEGA_SCHEDULER_VARIANTS", "0xEC")
+        monkeypatch.setenv("HPT_WF_SCHEDULER_VARIANTS", "0xEC")
+    else:
+        monkeypatch.setenv("HPT_SCHEDULER", "0")
+    gpu_ctx.upload(sc)
+    assert gpu_ctx.stats()["variant"] == {"cornell": 2, "heightfield4": 3, "heightfield8": 6, "bunny": 5}[name]
+    for mode, block in ((1, 256), (2, 256), (1, 100), (2, 64)):
+        gpu_ctx.stats_reset()
+        gpu_ctx.accum_clear()
+        gpu_ctx.render(mode, block, depth, 0, spp)
+        got = gpu_ctx.resolve(spp)
+        st = gpu_ctx.stats()
+        assert (st["closest_queries"], st["shadow_queries"], st["paths"]) == (ost["closest_queries"], ost["shadow_queries"], w * h * spp)
+        assert np.array_equal(got.view(np.int32), oracle.resolve(want_acc, spp).view(np.int32)), (mode, block)
