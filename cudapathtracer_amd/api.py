@@ -112,6 +112,7 @@ def _declare(L, H):
     L.hpt_context_destroy.argtypes = [vp]
     L.hpt_scene_upload.argtypes = [vp, C.POINTER(hpt_scene_desc)]
     L.hpt_set_seed.argtypes = [vp, u32]
+    L.hpt_set_integrator.argtypes = [vp, u32]
     L.hpt_set_wavefront_capacity.argtypes = [vp, u64]
     L.hpt_set_traversal.argtypes = [vp, C.c_int]
     L.hpt_octant_copies.argtypes = [C.POINTER(hpt_scene_desc), C.c_int, vp, vp]
@@ -134,6 +135,7 @@ def _declare(L, H):
     H.hpt_host_scene_named.argtypes = [C.c_char_p, C.c_char_p, i32, i32, i32, C.POINTER(vp)]
     H.hpt_host_scene_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, i32]
     H.hpt_host_scene_add_obj_transformed.argtypes = [vp, C.c_char_p, C.POINTER(hpt_material), vp, vp, vp]
+    H.hpt_host_scene_add_sphere.argtypes = [vp, vp, C.c_float, C.POINTER(hpt_material)]
     H.hpt_host_scene_create.argtypes = [i32, i32, vp, C.c_double, i32, C.POINTER(vp)]
     H.hpt_host_scene_add_obj.argtypes = [vp, C.c_char_p, C.POINTER(hpt_material)]
     H.hpt_host_scene_add_triangles.argtypes = [vp, vp, i32, C.POINTER(hpt_material)]
@@ -180,6 +182,7 @@ def _stream(stream):
 
 
 TRAVERSAL_REFERENCE, TRAVERSAL_CULLED = 0, 1
+INTEGRATOR_RUSSIAN_ROULETTE, INTEGRATOR_REGULARIZE = 1, 2
 
 
 class Scene:
@@ -244,6 +247,12 @@ class Scene:
         else:
             v = np.ascontiguousarray(mesh, np.float32).reshape(-1, 9)
             _ckh(self._H.hpt_host_scene_add_triangles(self._h, v.ctypes.data, len(v), C.byref(material)))
+        self._built = False
+
+    def AddSphere(self, center, radius, material):
+        """Scene::Add(Sphere*): center (3 floats), radius, a non-emitting material."""
+        c = np.asarray(center, np.float32)
+        _ckh(self._H.hpt_host_scene_add_sphere(self._h, c.ctypes.data, float(radius), C.byref(material)))
         self._built = False
 
     def buildBVH(self):
@@ -343,6 +352,12 @@ class Context:
 
     def set_seed(self, seed):
         _ck(self._L.hpt_set_seed(self._h, int(seed)))
+
+    def set_integrator(self, russian_roulette=False, regularize=False):
+        """hpt_set_integrator: the two steps of Scene::TracePath the reference switches off at compile time."""
+        _ck(self._L.hpt_set_integrator(self._h, (INTEGRATOR_RUSSIAN_ROULETTE if russian_roulette else 0)
+                                       | (INTEGRATOR_REGULARIZE if regularize else 0)))
+        return self
 
     def set_traversal(self, traversal):
         """TRAVERSAL_REFERENCE (default, bit-exact) or TRAVERSAL_CULLED; applies to the next upload."""

@@ -212,7 +212,7 @@ __device__ __forceinline__ void accumulate_pixel(int64_t* accum, uint32_t pixel,
 // (any lane may finish any pixel of its tile); a unit's accumulator is added to the global
 // buffer when its last path has ended.  Units are numbered chunk-major, so the chunks of an
 // expensive tile are spread over the launch.
-template <int kScene, bool kGlass, int kMaxBlock>
+template <int kScene, bool kExt, int kMaxBlock>
 __global__ void __launch_bounds__(kMaxBlock, (kMaxBlock == 256 ? HPT_MEGA_WAVES : 1))
 k_render_mega(DevScene S, int max_depth, uint32_t s_begin_all, uint32_t s_count_all, uint32_t s_chunk, uint32_t n_units,
               int64_t* __restrict__ accum, unsigned long long* __restrict__ stats, uint32_t* __restrict__ unit_counter) {
@@ -337,7 +337,7 @@ k_render_mega(DevScene S, int max_depth, uint32_t s_begin_all, uint32_t s_count_
             double t;
             ++n_rays;
             trace<kScene, false>(S, lds, tq, p.o, p.d, 0.0, tri, t PROF_PASS COUNT_PASS);
-            alive = shade_bounce<kScene, kGlass, 0x10000u>(S, lds, tq, p, tri, t, n_rays PROF_PASS COUNT_PASS) && p.depth < max_depth;
+            alive = shade_bounce<kScene, kExt, 0x10000u>(S, lds, tq, p, tri, t, n_rays PROF_PASS COUNT_PASS) && p.depth < max_depth;
             if (!alive) {
                 unsigned long long* acc = tile_acc + lane_gen * 192u + 3u * slot;
                 atomicAdd(acc + 0u, (unsigned long long)radiance_to_fixed(p.rad.x));
@@ -364,13 +364,13 @@ struct WfQueue {
     float4* a;  // o.xyz, bsdfSamplePdf
     float4* b;  // d.xyz, bits(pixel)
     float4* c;  // throughput.xyz, bits(sample)
-    float4* d;  // radiance.xyz, bits(depth | specular << 31)
+    float4* d;  // radiance.xyz, bits(depth | anyNonSpecularBounces << 30 | specularBounce << 31)
 };
 __device__ __forceinline__ void wf_store(const WfQueue& q, size_t i, const Path& p) {
     q.a[i] = make_float4(p.o.x, p.o.y, p.o.z, p.pdf);
     q.b[i] = make_float4(p.d.x, p.d.y, p.d.z, __uint_as_float(p.pixel));
     q.c[i] = make_float4(p.thr.x, p.thr.y, p.thr.z, __uint_as_float(p.sample));
-    q.d[i] = make_float4(p.rad.x, p.rad.y, p.rad.z, __uint_as_float((uint32_t)p.depth | (p.specular ? 0x80000000u : 0u)));
+    q.d[i] = make_float4(p.rad.x, p.rad.y, p.rad.z, __uint_as_float((uint32_t)p.depth | (p.specular ? 0x80000000u : 0u) | (p.diffused ? 0x40000000u : 0u)));
 }
 
 struct WfRecord {
@@ -397,8 +397,9 @@ __device__ __forceinline__ void wf_unpack(const WfRecord& r, Path& p) {
     p.sample = __float_as_uint(r.c.w);
     p.rad = mk(r.d.x, r.d.y, r.d.z);
     const uint32_t f = __float_as_uint(r.d.w);
-    p.depth = (int)(f & 0x7FFFFFFFu);
+    p.depth = (int)(f & 0x3FFFFFFFu);
     p.specular = (f >> 31) != 0;
+    p.diffused = (f & 0x40000000u) != 0;
 }
 
 // Wavefront queues are split into one SEGMENT per workgroup: workgroup b owns records
@@ -441,8 +442,9 @@ __global__ void k_wf_generate(DevScene S, uint32_t s_begin, uint64_t first, uint
                 // a dead record that the first bounce drops without tracing
                 p.o = p.d = p.thr = p.rad = mk(0.f);
                 p.pdf = 0.f;
-                p.depth = 0x7FFFFFFF;
+                p.depth = 0x3FFFFFFF;
                 p.specular = false;
+                p.diffused = false;
                 p.pixel = 0xFFFFFFFFu;
                 p.sample = sample;
             }
@@ -461,7 +463,7 @@ __global__ void k_wf_generate(DevScene S, uint32_t s_begin, uint64_t first, uint
 // (int64 atomics).  Survivors are compacted with __ballot + prefix popcount and one LDS atomic
 // per wave.  Segments are independent, so the bounce loop runs inside the kernel with workgroup
 // barriers only: one launch per batch, the scene staged once, no workgroup waits for another.
-template <int kScene, bool kGlass>
+template <int kScene, bool kExt>
 __global__ void __launch_bounds__(256)
 k_wf_bounces(DevScene S, int max_depth, uint32_t seg, WfQueue q0, WfQueue q1, const uint32_t* __restrict__ live,
              int64_t* __restrict__ accum, unsigned long long* __restrict__ stats) {
@@ -506,7 +508,7 @@ k_wf_bounces(DevScene S, int max_depth, uint32_t seg, WfQueue q0, WfQueue q1, co
                     double t;
                     ++n_closest;
                     trace<kScene, false>(S, lds, tq, p.o, p.d, 0.0, tri, t PROF_PASS COUNT_PASS);
-                    keep = shade_bounce<kScene, kGlass>(S, lds, tq, p, tri, t, n_shadow PROF_PASS COUNT_PASS) && p.depth < max_depth;
+                    keep = shade_bounce<kScene, kExt>(S, lds, tq, p, tri, t, n_shadow PROF_PASS COUNT_PASS) && p.depth < max_depth;
                     if (!keep) accumulate_pixel(accum, p.pixel, p.rad);
                 }
             }
@@ -561,7 +563,7 @@ enum { kLaneIdle = 0, kLaneWalk = 1, kLaneShadeA = 2, kLaneShadeB = 3 };
 //   void finish(p)                        per lane: the path has ended, add its radiance to the picture
 //   bool next_bounce(keep, p)             collective: the bounce is shaded and the path goes on (keep); returns
 //                                         whether THIS lane carries the path into its next bounce itself
-template <int kScene, bool kGlass, class Policy>
+template <int kScene, bool kExt, class Policy>
 __device__ __forceinline__ void schedule_wave(const DevScene& S, const float4* lds, TriQueue tq, int max_depth, Policy& pol COUNT_ARG) {
     using Trav = Traversal<kScene>;
     typename Trav::State W;
@@ -621,7 +623,7 @@ __device__ __forceinline__ void schedule_wave(const DevScene& S, const float4* l
             if (st == kLaneShadeA) {
                 f3 so, wi;
                 float tmax;
-                const int rc = shade_a(S, p, hit_tri, hit_t, so, wi, tmax, ls);
+                const int rc = shade_a<kExt>(S, p, hit_tri, hit_t, so, wi, tmax, ls);
                 if (rc == kShadeMiss) {
                     pol.finish(p);
                     st = kLaneIdle;
@@ -639,7 +641,7 @@ __device__ __forceinline__ void schedule_wave(const DevScene& S, const float4* l
             bool keep = false;
             const bool shading = st == kLaneShadeB;
             if (shading) {
-                shade_b<kGlass>(S, p, hit_tri, hit_t, lit && W.best < 0, W.d, ls);
+                shade_b<kExt>(S, p, hit_tri, hit_t, lit && W.best < 0, W.d, ls);
                 keep = p.depth < max_depth;
                 if (!keep) pol.finish(p);
                 st = kLaneIdle;
@@ -716,7 +718,7 @@ struct WfPolicy {
 #define HPT_SM_WAVES 1
 #endif
 // All bounces of a segment's paths, like k_wf_bounces, under the wave scheduler.
-template <int kScene, bool kGlass>
+template <int kScene, bool kExt>
 __global__ void __launch_bounds__(256, HPT_SM_WAVES)
 k_wf_bounces_sm(DevScene S, int max_depth, uint32_t seg, WfQueue q0, WfQueue q1, const uint32_t* __restrict__ live,
                 int64_t* __restrict__ accum, unsigned long long* __restrict__ stats) {
@@ -737,7 +739,7 @@ k_wf_bounces_sm(DevScene S, int max_depth, uint32_t seg, WfQueue q0, WfQueue q1,
         }
         __syncthreads();  // also: the records the previous bounce stored are visible to the whole workgroup
         WfPolicy pol{(bounce & 1) ? q1 : q0, (bounce & 1) ? q0 : q1, seg_base, count, &s_next, &s_out, accum, lane};
-        schedule_wave<kScene, kGlass>(S, lds, tq, max_depth, pol COUNT_PASS);
+        schedule_wave<kScene, kExt>(S, lds, tq, max_depth, pol COUNT_PASS);
         n_closest += pol.n_closest;
         n_shadow += pol.n_shadow;
         __syncthreads();
@@ -867,7 +869,7 @@ struct MegaPolicy {
 #ifndef HPT_MEGA_SM_WAVES
 #define HPT_MEGA_SM_WAVES 4
 #endif
-template <int kScene, bool kGlass, int kMaxBlock>
+template <int kScene, bool kExt, int kMaxBlock>
 __global__ void __launch_bounds__(kMaxBlock, (kMaxBlock == 256 ? HPT_MEGA_SM_WAVES : 1))
 k_render_mega_sm(DevScene S, int max_depth, uint32_t s_begin_all, uint32_t s_count_all, uint32_t s_chunk, uint32_t n_units,
                  int64_t* __restrict__ accum, unsigned long long* __restrict__ stats, uint32_t* __restrict__ unit_counter) {
@@ -885,7 +887,7 @@ k_render_mega_sm(DevScene S, int max_depth, uint32_t s_begin_all, uint32_t s_cou
     MegaPolicy pol{S, s_begin_all, s_count_all, s_chunk, n_units, reinterpret_cast<unsigned long long*>(accum), stats, unit_counter,
                    tile_acc, lane, wave_lanes, W, H, tiles_x, tiles_x * ((H + 7u) >> 3)};
     COUNT_DECL;
-    schedule_wave<kScene, kGlass>(S, lds, tq, max_depth, pol COUNT_PASS);
+    schedule_wave<kScene, kExt>(S, lds, tq, max_depth, pol COUNT_PASS);
     pol.close();
     COUNT_FLUSH(stats);
 }
@@ -937,7 +939,13 @@ struct hpt_ctx {
     int num_cus = 256;
     bool has_scene = false;
     int traversal = HPT_TRAVERSAL_REFERENCE;
-    bool has_glass = false;  // some material is Material::Type::Glass: selects the kernels that carry its branch
+    // the scene has a Glass material or a sphere, or the integrator runs Russian roulette / path
+    // regularisation: selects the kernels built with kExt, which carry those branches
+    bool extended = false;
+    bool scene_extended = false;      // the scene's share of `extended`
+    bool has_sphere = false;          // a record of the triangle array is a sphere: no marking variant
+    uint32_t integrator = 0;          // kIntegratorRoulette | kIntegratorRegularize (hpt_set_integrator)
+    float russian_roulette = 0.8f;    // Scene::RussianRoulette (common/Scene.hpp:30)
     DevScene S{};
     // scene arrays (device)
     float4* d_nodes = nullptr;
@@ -1504,7 +1512,7 @@ int render_launch(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sam
         const bool scheduler = has_scheduler(S.variant) && !(sched_env && atoi(sched_env) == 0) && ((mega_mask >> S.variant) & 1u);
 #define HPT_MEGA_KERNEL(kS, kG, kB) (scheduler ? reinterpret_cast<const void*>(&k_render_mega_sm<has_scheduler(kS) ? kS : kScenePair, kG, kB>) \
                                                : reinterpret_cast<const void*>(&k_render_mega<kS, kG, kB>))
-        HPT_DISPATCH_RENDER(S.variant, ctx->has_glass, {
+        HPT_DISPATCH_RENDER(S.variant, ctx->extended, {
             if (block <= 256) {
                 if (lds_mega > 48u * 1024u) HIP_TRY(hipFuncSetAttribute(HPT_MEGA_KERNEL(kS, kG, 256), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mega));
                 if (scheduler) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_mega_sm<has_scheduler(kS) ? kS : kScenePair, kG, 256>, block, lds_mega));
@@ -1523,7 +1531,7 @@ int render_launch(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sam
             const uint32_t units = tiles * ((n + chunk - 1u) / chunk);
             const uint32_t blocks = std::min(resident, (units + waves_per_block - 1u) / waves_per_block);
             HIP_TRY(hipMemsetAsync(unit_counter, 0, sizeof(uint32_t), stream));
-            HPT_DISPATCH_RENDER(S.variant, ctx->has_glass, {
+            HPT_DISPATCH_RENDER(S.variant, ctx->extended, {
                 constexpr int kT = has_scheduler(kS) ? kS : kScenePair;  // (never launched for variants without a Traversal<>)
                 if (scheduler) {
                     if (block <= 256) hipLaunchKernelGGL((k_render_mega_sm<kT, kG, 256>), dim3(blocks), dim3(block), lds_mega, stream, S, max_depth, s, n, chunk, units, accum, ctx->d_stats, unit_counter);
@@ -1551,7 +1559,7 @@ int render_launch(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sam
         const char* sched_mask = getenv("HPT_WF_SCHEDULER_VARIANTS");
         const uint32_t wf_mask = sched_mask ? (uint32_t)strtoul(sched_mask, nullptr, 0) : kWfSchedulerVariants;
         const bool scheduler = has_scheduler(S.variant) && !(sched_env && atoi(sched_env) == 0) && !(sched_env2 && atoi(sched_env2) == 0) && ((wf_mask >> S.variant) & 1u);
-        HPT_DISPATCH_RENDER(S.variant, ctx->has_glass, {
+        HPT_DISPATCH_RENDER(S.variant, ctx->extended, {
             if constexpr (has_scheduler(kS)) {
                 if (scheduler) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_bounces_sm<kS, kG>, wblock, lds_bytes(S, wblock)));
                 else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_bounces<kS, kG>, wblock, lds_bytes(S, wblock)));
@@ -1585,7 +1593,7 @@ int render_launch(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sam
             const uint32_t count = (uint32_t)((total - first < batch) ? total - first : batch);
             hipLaunchKernelGGL(k_wf_generate, dim3(segments), dim3(gblock), 0, stream, S, sample_begin, first, count, (uint32_t)lanes, seg, q[0], live, ctx->d_stats);
             HIP_TRY(hipGetLastError());
-            HPT_DISPATCH_RENDER(S.variant, ctx->has_glass, {
+            HPT_DISPATCH_RENDER(S.variant, ctx->extended, {
                 if constexpr (has_scheduler(kS)) {
                     if (scheduler) hipLaunchKernelGGL((k_wf_bounces_sm<kS, kG>), dim3(segments), dim3(wblock), lds_bytes(S, wblock), stream, S, max_depth, seg, q[0], q[1], live, accum, ctx->d_stats);
                     else hipLaunchKernelGGL((k_wf_bounces<kS, kG>), dim3(segments), dim3(wblock), lds_bytes(S, wblock), stream, S, max_depth, seg, q[0], q[1], live, accum, ctx->d_stats);
@@ -1682,11 +1690,12 @@ int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* sc) {
     ALLOC_TRY(ctx->d_node_area, nn * 4, "node_area");
     ALLOC_TRY(ctx->d_tris, nt * 64, "tris");
     ALLOC_TRY(ctx->d_tri_v12, nt * 32, "tri_v12");
-    ALLOC_TRY(ctx->d_mats, sc->num_materials * sizeof(DevMaterial), "mats");
+    ALLOC_TRY(ctx->d_mats, 2 * (size_t)sc->num_materials * sizeof(DevMaterial), "mats");
     ALLOC_TRY(ctx->d_lights, (sc->num_lights ? sc->num_lights : 1) * sizeof(DevLight), "lights");
     HIP_TRY(hipMemcpy(ctx->d_nodes, sc->nodes, nn * 32, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->d_node_area, sc->node_area, nn * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->d_tri_v12, sc->tri_v12, nt * 32, hipMemcpyHostToDevice));
+    std::vector<float> tris(sc->tris, sc->tris + nt * 16);  // the device copy of the triangle records, uploaded below
     {
         // derived tables (see DevMaterial / DevLight); plain float arithmetic in the
         // reference's order, this file is compiled without FMA contraction
@@ -1695,10 +1704,19 @@ int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* sc) {
             const float tx = c[0] * .2126f, ty = c[1] * .7152f, tz = c[2] * .0722f;
             return tx + ty + tz;
         };
-        std::vector<DevMaterial> mats(sc->num_materials);
+        // two tables back to back: the materials as given, and after Material::regularize()
+        // (common/Material.hpp:164-171: alpha = sqrt(roughness) < 0.3 -> clamp(2 alpha, 0.1, 0.3)^2)
+        std::vector<DevMaterial> mats(2 * (size_t)sc->num_materials);
         bool glass = false;
-        for (uint32_t i = 0; i < sc->num_materials; ++i) {
-            const hpt_material& m = sc->materials[i];
+        for (uint32_t i = 0; i < 2 * sc->num_materials; ++i) {
+            hpt_material m = sc->materials[i % sc->num_materials];
+            if (i >= sc->num_materials) {
+                float alpha_x = std::sqrt(m.roughness);
+                if (alpha_x < 0.3f) {
+                    alpha_x = std::min(std::max(2 * alpha_x, 0.1f), 0.3f);
+                    m.roughness = alpha_x * alpha_x;
+                }
+            }
             DevMaterial& d = mats[i];
             std::memset(&d, 0, sizeof d);
             d.type = m.type;
@@ -1730,7 +1748,6 @@ int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* sc) {
             d.root_node = l.root_node;
             for (int c = 0; c < 3; ++c) d.emission[c] = sc->materials[l.material].emission[c];
         }
-        std::vector<float> tris(sc->tris, sc->tris + nt * 16);
         for (size_t t = 0; t < nt; ++t) {
             int32_t mat;
             std::memcpy(&mat, &tris[16 * t + 7], 4);
@@ -1738,23 +1755,16 @@ int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* sc) {
             // luminance(Le) * 2 * pi * triangleArea / sumLightPower (common/Scene.hpp:179, :215)
             tris[16 * t + 3] = lum(sc->materials[mat].emission) * 2.f * pi * area / sc->sum_light_power;
         }
-        // Word 15 of the device copy (the mesh index, which no kernel reads): for scenes of up to 32
-        // triangles the mask of the triangles that have this triangle's normal (a zero of either
-        // sign counts as the same value: it contributes +-0 to dot(d, n) either way).  The
-        // back-face filter of the 32-triangle marking variant settles a whole group with one test.
-        if (nt <= 32) {
-            auto same = [](float a, float b) { return (a == 0.f && b == 0.f) || std::memcmp(&a, &b, 4) == 0; };
-            for (size_t t = 0; t < nt; ++t) {
-                uint32_t group = 0;
-                for (size_t u = 0; u < nt; ++u)
-                    if (same(tris[16 * t + 12], tris[16 * u + 12]) && same(tris[16 * t + 13], tris[16 * u + 13]) && same(tris[16 * t + 14], tris[16 * u + 14]))
-                        group |= 1u << u;
-                std::memcpy(&tris[16 * t + 15], &group, 4);
-            }
+        bool has_sphere = false;
+        for (size_t t = 0; t < nt; ++t) {
+            uint32_t w15;
+            std::memcpy(&w15, &tris[16 * t + 15], 4);
+            if (w15 & kSphereBit) has_sphere = true;
         }
-        HIP_TRY(hipMemcpy(ctx->d_tris, tris.data(), nt * 64, hipMemcpyHostToDevice));
+        ctx->has_sphere = has_sphere;
         HIP_TRY(hipMemcpy(ctx->d_mats, mats.data(), mats.size() * sizeof(DevMaterial), hipMemcpyHostToDevice));
-        ctx->has_glass = glass;
+        ctx->scene_extended = glass || has_sphere;
+        ctx->extended = ctx->scene_extended || ctx->integrator != 0;
         HIP_TRY(hipMemcpy(ctx->d_lights, lights.data(), lights.size() * sizeof(DevLight), hipMemcpyHostToDevice));
     }
     // Two-child records of the same tree (see DevScene::pairs).  Interior node i has the children
@@ -1809,6 +1819,9 @@ int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* sc) {
     DevScene& S = ctx->S;
     const uint32_t seed = S.seed;
     S = DevScene{};
+    S.integrator = ctx->integrator;
+    S.roulette_q = 1 - ctx->russian_roulette;
+    S.has_spheres = ctx->has_sphere ? 1u : 0u;
     S.nodes = ctx->d_nodes;
     S.node_area = ctx->d_node_area;
     S.tris = ctx->d_tris;
@@ -1843,8 +1856,9 @@ int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* sc) {
     const bool fits = f4 * 16ull <= kLdsLimit, fits_pair = f4_pair * 16ull <= kLdsLimit;
     const bool fits_tiny = f4_tiny * 16ull <= kLdsLimitTiny;
     const bool pair_ok = num_pairs > 0 && stack_depth <= kMaxStackDepth;
-    if (fits_tiny && nt <= 32) S.variant = kSceneTiny32;
-    else if (fits_tiny && nt <= 64) S.variant = kSceneTiny64;
+    const bool tiny_ok = fits_tiny && !ctx->has_sphere;  // the marking variants test triangles only
+    if (tiny_ok && nt <= 32) S.variant = kSceneTiny32;
+    else if (tiny_ok && nt <= 64) S.variant = kSceneTiny64;
     else if (pair_ok) S.variant = fits_pair ? kScenePairLds : kScenePair;
     else S.variant = fits ? kSceneLds : kSceneGlobal;
     // the culled walk packs a record index into 22 bits of a stack entry
@@ -1855,11 +1869,26 @@ int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* sc) {
         if (v == kScenePairCull && cull_ok) S.variant = kScenePairCull;
         if (v == kSceneGlobal) S.variant = kSceneGlobal;
         else if (v == kSceneLds && fits) S.variant = kSceneLds;
-        else if (v == kSceneTiny64 && fits_tiny && nt <= 64) S.variant = kSceneTiny64;
-        else if (v == kSceneTiny32 && fits_tiny && nt <= 32) S.variant = kSceneTiny32;
+        else if (v == kSceneTiny64 && tiny_ok && nt <= 64) S.variant = kSceneTiny64;
+        else if (v == kSceneTiny32 && tiny_ok && nt <= 32) S.variant = kSceneTiny32;
         else if (v == kScenePair && pair_ok) S.variant = kScenePair;
         else if (v == kScenePairLds && pair_ok && fits_pair) S.variant = kScenePairLds;
     }
+    // Word 15 of the device copy (the mesh index, which no kernel reads): for scenes of up to 32
+    // triangles the mask of the triangles that have this triangle's normal (a zero of either
+    // sign counts as the same value: it contributes +-0 to dot(d, n) either way).  The
+    // back-face filter of the 32-triangle marking variant settles a whole group with one test.
+    if (S.variant == kSceneTiny32) {
+        auto same = [](float a, float b) { return (a == 0.f && b == 0.f) || std::memcmp(&a, &b, 4) == 0; };
+        for (size_t t = 0; t < nt; ++t) {
+            uint32_t group = 0;
+            for (size_t u = 0; u < nt; ++u)
+                if (same(tris[16 * t + 12], tris[16 * u + 12]) && same(tris[16 * t + 13], tris[16 * u + 13]) && same(tris[16 * t + 14], tris[16 * u + 14]))
+                    group |= 1u << u;
+            std::memcpy(&tris[16 * t + 15], &group, 4);
+        }
+    }
+    HIP_TRY(hipMemcpy(ctx->d_tris, tris.data(), nt * 64, hipMemcpyHostToDevice));
     if (S.variant == kScenePairCull) {
         S.stack_depth = stack_depth_any;
         double diag2 = 0;
@@ -1896,6 +1925,16 @@ int hpt_set_traversal(hpt_ctx* ctx, int traversal) {
     if (traversal != HPT_TRAVERSAL_REFERENCE && traversal != HPT_TRAVERSAL_CULLED)
         return fail(HPT_ERR_INVALID_ARGUMENT, "traversal %d is neither HPT_TRAVERSAL_REFERENCE nor HPT_TRAVERSAL_CULLED", traversal);
     ctx->traversal = traversal;
+    return HPT_OK;
+}
+
+int hpt_set_integrator(hpt_ctx* ctx, uint32_t flags) {
+    if (!ctx) return fail(HPT_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (flags & ~(uint32_t)(HPT_INTEGRATOR_RUSSIAN_ROULETTE | HPT_INTEGRATOR_REGULARIZE))
+        return fail(HPT_ERR_INVALID_ARGUMENT, "unknown integrator flag in 0x%x", flags);
+    ctx->integrator = flags;
+    ctx->S.integrator = flags;
+    ctx->extended = ctx->scene_extended || flags != 0;
     return HPT_OK;
 }
 

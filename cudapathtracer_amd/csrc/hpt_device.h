@@ -274,7 +274,17 @@ struct DevScene {
     // box-entry distance into the 10 bits above a stack entry's record index (and its inverse)
     float cull_slack, cull_qscale, cull_qinv;
     unsigned long long* prof;  // diagnostic builds only (3 x kProfSections totals), else null
+    // kernels built with kExt only: the integrator's optional steps (kIntegratorRoulette |
+    // kIntegratorRegularize), 1 - Scene::RussianRoulette, and `mats` holds a second table behind
+    // the first: the materials after Material::regularize()
+    uint32_t integrator;
+    float roulette_q;
+    uint32_t has_spheres;  // some record of `tris` is a sphere (then word 15 is the mesh index everywhere, never a group mask)
 };
+enum : uint32_t { kIntegratorRoulette = 1u, kIntegratorRegularize = 2u };
+// word 15 of a record of the triangle array with this bit set: the record is a sphere
+//   center.xyz, 0 | radius, radius^2, 0, bits(material) | 0, 0, 0, bits(prim id) | 0, 0, 0, bits(mesh | kSphereBit)
+constexpr uint32_t kSphereBit = 0x80000000u;
 
 // ------------------------------------------------------------ traversal -----
 // Scene residency / traversal variant, chosen at upload from the scene size:
@@ -404,13 +414,52 @@ HD double reciprocal_of_float(float x) {
     return __builtin_fma(rem, r, r);
 }
 
+// solveQuadratic (common/MathUtils.hpp:86-100): float coefficients; its sqrt is the double one, and
+// the sums / products around it and the double literal -0.5 are double, narrowed on assignment
+HD bool solveQuadratic(float a, float b, float c, float& x0, float& x1) {
+    const float discr = b * b - 4 * a * c;
+    if (discr < 0) return false;
+    if (discr == 0) {
+        x0 = x1 = (float)(-0.5 * (double)b / (double)a);
+    } else {
+        const double root = __builtin_sqrt((double)discr);
+        const float q = (b > 0) ? (float)(-0.5 * ((double)b + root)) : (float)(-0.5 * ((double)b - root));
+        x0 = q / a;
+        x1 = c / q;
+    }
+    if (x0 > x1) {
+        const float t = x0;
+        x0 = x1;
+        x1 = t;
+    }
+    return true;
+}
+// Sphere::getIntersection (common/Sphere.hpp:49-69, commented out in the reference): the nearer
+// root that is not negative, no back-face rule
+HD bool sphere_hit(const float4* __restrict__ T, int rec, f3 o, f3 d, double& t_out) {
+    const f3 center = xyz(T[4 * rec]);
+    const float radius2 = T[4 * rec + 1].y;
+    const f3 L = o - center;
+    const float a = dot(d, d);
+    const float b = 2 * dot(d, L);
+    const float c = dot(L, L) - radius2;
+    float t0, t1;
+    if (!solveQuadratic(a, b, c, t0, t1)) return false;
+    if (t0 < 0) t0 = t1;
+    if (t0 < 0) return false;
+    t_out = (double)t0;
+    return true;
+}
+
 // Triangle::getIntersection (common/Triangle.hpp:164-198): back-face cull,
 // float cross/dot products, double det, 1/det, u, v, t.
 // kCulled: the caller has already dropped back-facing triangles.
 template <bool kCulled = false>
 HD bool tri_hit(const float4* __restrict__ T, int tri, f3 o, f3 d, double& t_out) {
     if constexpr (!kCulled) {
-        const f3 n = xyz(T[4 * tri + 3]);
+        const float4 n4 = T[4 * tri + 3];
+        if (__float_as_uint(n4.w) & kSphereBit) return sphere_hit(T, tri, o, d, t_out);  // (never in the scenes the marking variants serve)
+        const f3 n = xyz(n4);
         if (dot(d, n) > 0) return false;
     }
     const f3 v0 = xyz(T[4 * tri]), e1 = xyz(T[4 * tri + 1]), e2 = xyz(T[4 * tri + 2]);
@@ -1165,9 +1214,9 @@ HD void glass_eval(float rsq, float rsq_minus_1, float roughness, float ior, f3 
 }
 
 // Material::pdf and Material::bsdf (Material.hpp:257-312, :315-384), evaluated together
-// because the integrator always needs both.  kGlass = false compiles the Glass branch out:
+// because the integrator always needs both.  kExt = false compiles the Glass branch out:
 // kernels for scenes without a glass material pay nothing for it in registers.
-template <bool kGlass>
+template <bool kExt>
 HD void mat_eval(const DevMaterial& m, f3 src, f3 out, f3 normal, f3& bsdf, float& pdf) {
     if (m.type == 0) {
         const bool front = dot(out, normal) > 0.0f;
@@ -1175,7 +1224,7 @@ HD void mat_eval(const DevMaterial& m, f3 src, f3 out, f3 normal, f3& bsdf, floa
         bsdf = front ? mk(m.albedo_over_pi[0], m.albedo_over_pi[1], m.albedo_over_pi[2]) : mk(0.0f);
         return;
     }
-    if constexpr (kGlass) {
+    if constexpr (kExt) {
         if (m.type == 2) {
             glass_eval(m.rsq, m.rsq_minus_1, m.roughness, m.ior, src, out, normal, bsdf, pdf);
             return;
@@ -1213,7 +1262,7 @@ HD f3 glass_direction(f3 observation_dir, f3 micro, float ior, float r2) {
     return refract(observation_dir, micro, ior);
 }
 // Material::sample (Material.hpp:186-219); r0/r1/r2 are draws kSlotBsdf0/1/2
-template <bool kGlass>
+template <bool kExt>
 HD f3 mat_sample(const DevMaterial& m, float r0, float r1, float r2, f3 ray_out_dir, f3 normal) {
     if (m.type == 0) return sampleHemisphereCosine(normal, r0, r1);
     const float theta = portable_acos(sqrt_rn((1.0f - r0) / (m.rsq_minus_1 * r0 + 1.0f)));
@@ -1222,12 +1271,31 @@ HD f3 mat_sample(const DevMaterial& m, float r0, float r1, float r2, f3 ray_out_
     portable_sincos(theta, st, ct);
     portable_sincos(phi, sp, cp);
     const f3 micro = local_to_world(mk(st * cp, st * sp, ct), normal);
-    if constexpr (kGlass) {
+    if constexpr (kExt) {
         if (m.type == 2) return glass_direction(-ray_out_dir, micro, m.ior, r2);
     }
     return reflect(-ray_out_dir, micro);
 }
 
+// Material and shading normal of a hit.  kExt: the table of regularised materials serves a path
+// that has left a non-specular surface behind when the integrator regularises (Scene.hpp:186-189);
+// a sphere's normal is normalize(coords - center) (Sphere.hpp:62).
+template <bool kExt>
+HD const DevMaterial& hit_material(const DevScene& S, int hit_tri, bool diffused) {
+    uint32_t m = (uint32_t)__float_as_int(S.tris[4 * hit_tri + 1].w);
+    if constexpr (kExt) {
+        if ((S.integrator & kIntegratorRegularize) && diffused) m += S.num_mats;
+    }
+    return S.mats[m];
+}
+template <bool kExt>
+HD f3 hit_normal(const DevScene& S, int hit_tri, f3 coords) {
+    const float4 n4 = S.tris[4 * hit_tri + 3];
+    if constexpr (kExt) {
+        if (S.has_spheres && (__float_as_uint(n4.w) & kSphereBit)) return normalize(coords - xyz(S.tris[4 * hit_tri]));
+    }
+    return xyz(n4);
+}
 // Per-path state carried between bounces (PathSegment, common/Ray.hpp:36-52,
 // minus the RNG state, which the keyed stream makes unnecessary).
 struct Path {
@@ -1236,8 +1304,23 @@ struct Path {
     float pdf;        // bsdfSamplePdf of the previous bounce
     int depth;        // bounces done so far (== loop index of Scene::castRay)
     bool specular;    // specularBounce
+    bool diffused;    // anyNonSpecularBounces (read by kernels built with kExt only)
     uint32_t pixel, sample;
 };
+
+// the tail of a bounce that went on (Scene.hpp:243-264): anyNonSpecularBounces, and Russian
+// roulette AS WRITTEN there -- its `break` leaves only the function's while(true) wrapper, so a
+// "killed" bounce merely goes without the 1 / (1 - q) compensation; the path is not ended
+template <bool kExt>
+HD void bounce_tail(const DevScene& S, Path& p, float roulette_draw) {
+    if constexpr (kExt) {
+        p.diffused = p.diffused || !p.specular;
+        if (S.integrator & kIntegratorRoulette) {
+            if (p.depth > 1 && !(roulette_draw < S.roulette_q)) p.thr = p.thr / (1.f - S.roulette_q);
+        }
+    }
+}
+
 
 // Renderer.cpp:32-39 / CudaPathTrace.cu:39-59: jittered primary ray (one jitter
 // value for both axes), throughput 1, radiance 0.
@@ -1254,6 +1337,7 @@ HD void generate_camera_path(const DevScene& S, uint32_t pixel, uint32_t sample,
     p.pdf = 0.0f;
     p.depth = 0;
     p.specular = false;
+    p.diffused = false;
     p.pixel = pixel;
     p.sample = sample;
 }
@@ -1262,7 +1346,7 @@ HD void generate_camera_path(const DevScene& S, uint32_t pixel, uint32_t sample,
 // (hit_tri, hit_t); hit_tri < 0 = miss.  Returns false when the path ends on
 // this bounce for the reason "missed the scene" (remainingBounces = 0, :156-161);
 // the caller ends it after max_depth bounces otherwise.  Counts shadow queries.
-template <int kScene, bool kGlass, uint32_t kShadowInc = 1u>
+template <int kScene, bool kExt, uint32_t kShadowInc = 1u>
 HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, Path& p, int hit_tri, double hit_t,
                      uint32_t& shadow_queries PROF_ARG COUNT_ARG) {
     bool alive = true;
@@ -1278,7 +1362,7 @@ HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, TriQueue
         // the device copies in global memory (not the LDS stage): word 3 = light pdf
         const f3 coords = p.o + p.d * (float)hit_t;  // Ray::operator(), Ray.hpp:27
         {
-            const DevMaterial& material = S.mats[__float_as_int(S.tris[4 * hit_tri + 1].w)];
+            const DevMaterial& material = hit_material<kExt>(S, hit_tri, p.diffused);
             if (material.flags & kMatEmitting) {  // :164-184
                 const f3 radiance = mk(material.emission[0], material.emission[1], material.emission[2]);
                 if (p.depth == 0 || p.specular) {
@@ -1351,14 +1435,14 @@ HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, TriQueue
 #endif
                 if (occ_tri < 0) {
                     asm volatile("" : "+v"(hit_tri), "+v"(light));  // forget what was derived from them
-                    const f3 normal = xyz(S.tris[4 * hit_tri + 3]);
-                    const DevMaterial& material = S.mats[__float_as_int(S.tris[4 * hit_tri + 1].w)];
+                    const f3 normal = hit_normal<kExt>(S, hit_tri, coords);
+                    const DevMaterial& material = hit_material<kExt>(S, hit_tri, p.diffused);
                     const DevLight& L = S.lights[light];
                     const f3 lemit = mk(L.emission[0], L.emission[1], L.emission[2]);
                     const f3 wo = -p.d;
                     f3 bsdf;
                     float bsdfPdf;
-                    mat_eval<kGlass>(material, wi, wo, normal, bsdf, bsdfPdf);
+                    mat_eval<kExt>(material, wi, wo, normal, bsdf, bsdfPdf);
                     const float cos_theta = satDot(normal, wi);
                     const float weight = powerHeuristic(lightPdf, bsdfPdf);
                     p.rad = p.rad + p.thr * lemit * bsdf * cos_theta * cos_theta_prime / r2 / lightSamplePdf * weight;
@@ -1368,14 +1452,14 @@ HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, TriQueue
 
         // :230-250
         asm volatile("" : "+v"(hit_tri));
-        const f3 normal = xyz(S.tris[4 * hit_tri + 3]);
-        const DevMaterial& material = S.mats[__float_as_int(S.tris[4 * hit_tri + 1].w)];
+        const f3 normal = hit_normal<kExt>(S, hit_tri, coords);
+        const DevMaterial& material = hit_material<kExt>(S, hit_tri, p.diffused);
         const u4 rb = philox4x32_10((uint32_t)p.depth, 1u, S.seed, 0u, p.pixel, p.sample);
         const f3 wo = -p.d;
-        const f3 wi = mat_sample<kGlass>(material, u01(rb.x), u01(rb.y), u01(rb.z), wo, normal);
+        const f3 wi = mat_sample<kExt>(material, u01(rb.x), u01(rb.y), u01(rb.z), wo, normal);
         f3 bsdf;
         float pdf;
-        mat_eval<kGlass>(material, wi, wo, normal, bsdf, pdf);
+        mat_eval<kExt>(material, wi, wo, normal, bsdf, pdf);
         p.pdf = pdf;
         if (pdf < kEpsilon5) break;  // the path keeps its ray and re-traces it (:238-240)
         p.specular = (material.flags & kMatSpecular) != 0;
@@ -1383,6 +1467,7 @@ HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, TriQueue
         p.thr = p.thr * (bsdf * cos_theta / pdf);
         p.o = coords + wi * kEpsilon5;
         p.d = wi;
+        bounce_tail<kExt>(S, p, u01(rb.w));
     } while (false);
 
 #ifdef HPT_PROFILE
@@ -1408,6 +1493,7 @@ HD void finish_bounce(Path& p) {  // :268-271
     if (isnan(p.rad.x) || isnan(p.rad.y) || isnan(p.rad.z) || isinf(p.rad.x) || isinf(p.rad.y) || isinf(p.rad.z))
         p.rad = mk(0.0f);
 }
+template <bool kExt>
 HD int shade_a(const DevScene& S, Path& p, int hit_tri, double hit_t, f3& so, f3& wi, float& tmax, LightSample& ls) {
     if (hit_tri < 0) {
         finish_bounce(p);
@@ -1415,7 +1501,7 @@ HD int shade_a(const DevScene& S, Path& p, int hit_tri, double hit_t, f3& so, f3
     }
     const f3 coords = p.o + p.d * (float)hit_t;  // Ray::operator(), Ray.hpp:27
     {
-        const DevMaterial& material = S.mats[__float_as_int(S.tris[4 * hit_tri + 1].w)];
+        const DevMaterial& material = hit_material<kExt>(S, hit_tri, p.diffused);
         if (material.flags & kMatEmitting) {  // :164-184
             const f3 radiance = mk(material.emission[0], material.emission[1], material.emission[2]);
             if (p.depth == 0 || p.specular) {
@@ -1478,28 +1564,28 @@ HD int shade_a(const DevScene& S, Path& p, int hit_tri, double hit_t, f3& so, f3
     return kShadeShadowRay;
 }
 // lit: a shadow ray towards the light sample `ls` along `wi` was traced and found nothing
-template <bool kGlass>
+template <bool kExt>
 HD void shade_b(const DevScene& S, Path& p, int hit_tri, double hit_t, bool lit, f3 wi_light, const LightSample& ls) {
     const f3 coords = p.o + p.d * (float)hit_t;
-    const f3 normal = xyz(S.tris[4 * hit_tri + 3]);
-    const DevMaterial& material = S.mats[__float_as_int(S.tris[4 * hit_tri + 1].w)];
+    const f3 normal = hit_normal<kExt>(S, hit_tri, coords);
+    const DevMaterial& material = hit_material<kExt>(S, hit_tri, p.diffused);
     const f3 wo = -p.d;
     if (lit) {  // :208-227
         const DevLight& L = S.lights[ls.light];
         const f3 lemit = mk(L.emission[0], L.emission[1], L.emission[2]);
         f3 bsdf;
         float bsdfPdf;
-        mat_eval<kGlass>(material, wi_light, wo, normal, bsdf, bsdfPdf);
+        mat_eval<kExt>(material, wi_light, wo, normal, bsdf, bsdfPdf);
         const float cos_theta = satDot(normal, wi_light);
         const float weight = powerHeuristic(ls.lightPdf, bsdfPdf);
         p.rad = p.rad + p.thr * lemit * bsdf * cos_theta * ls.cos_theta_prime / ls.r2 / ls.lightSamplePdf * weight;
     }
     // :230-250
     const u4 rb = philox4x32_10((uint32_t)p.depth, 1u, S.seed, 0u, p.pixel, p.sample);
-    const f3 wi = mat_sample<kGlass>(material, u01(rb.x), u01(rb.y), u01(rb.z), wo, normal);
+    const f3 wi = mat_sample<kExt>(material, u01(rb.x), u01(rb.y), u01(rb.z), wo, normal);
     f3 bsdf;
     float pdf;
-    mat_eval<kGlass>(material, wi, wo, normal, bsdf, pdf);
+    mat_eval<kExt>(material, wi, wo, normal, bsdf, pdf);
     p.pdf = pdf;
     if (!(pdf < kEpsilon5)) {  // else the path keeps its ray and re-traces it (:238-240)
         p.specular = (material.flags & kMatSpecular) != 0;
@@ -1507,6 +1593,7 @@ HD void shade_b(const DevScene& S, Path& p, int hit_tri, double hit_t, bool lit,
         p.thr = p.thr * (bsdf * cos_theta / pdf);
         p.o = coords + wi * kEpsilon5;
         p.d = wi;
+        bounce_tail<kExt>(S, p, u01(rb.w));
     }
     finish_bounce(p);
 }

@@ -36,6 +36,7 @@ void HipRenderer::PrepareRender(const Scene& scene) {
         if (k == 0) ctx = c;
         else extra_ctx.push_back(c);
         check(hpt_set_traversal(c, traversal), "hpt_set_traversal");
+        check(hpt_set_integrator(c, integrator), "hpt_set_integrator");
         check(hpt_scene_upload(c, &desc), "hpt_scene_upload");
     }
     framebuffer.assign(num_pixels, Vec3(0.f));

@@ -33,6 +33,9 @@ public:
     // HPT_TRAVERSAL_REFERENCE (0, bit-exact, default) or HPT_TRAVERSAL_CULLED (1, opt-in); no
     // counterpart in the reference
     int traversal = 0;
+    // HPT_INTEGRATOR_RUSSIAN_ROULETTE | HPT_INTEGRATOR_REGULARIZE: the steps of Scene::TracePath the
+    // reference switches off at compile time (common/Scene.hpp:141-142); 0 = the reference's behaviour
+    unsigned integrator = 0;
     ~HipRenderer() override;
     void SetMode(HipRenderMode mode);
     void PrepareRender(const Scene& scene);

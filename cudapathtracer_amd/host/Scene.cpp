@@ -23,8 +23,17 @@ void put_int(float* dst, int32_t v) { std::memcpy(dst, &v, 4); }
 }  // namespace
 
 // light bookkeeping as common/Scene.hpp:47-56
+void Scene::Add(Sphere* sphere) {
+    sphere_owner_.emplace_back(sphere);
+    if (sphere->material.emitting()) throw std::runtime_error("Scene::Add: a sphere cannot be a light (Scene::sampleLight samples meshes only)");
+    if (!(sphere->radius > 0.f)) throw std::runtime_error("Scene::Add: a sphere needs a positive radius");
+    objects.push_back(ObjectRef{true, (int)spheres.size()});
+    spheres.push_back(sphere);
+}
+
 void Scene::Add(MeshTriangle* mesh) {
     mesh_owner_.emplace_back(mesh);
+    objects.push_back(ObjectRef{false, (int)meshes.size()});
     meshes.push_back(mesh);
     num_meshes = (int)meshes.size();
     if (mesh->material.emitting()) {
@@ -40,27 +49,30 @@ float Scene::cameraScale() const {
     return (float)std::tan((double)half_rad);
 }
 
-// Builds the two-level BVH (top level over meshes, one nested BVH per mesh,
-// common/Scene.cpp:9-23 + common/BVH.cpp:92-104) and flattens it: every
-// top-level leaf is replaced by its mesh's subtree, whose exits continue at the
-// node that follows the leaf.
+// Builds the two-level BVH (top level over the objects -- meshes and spheres in Add order --, one
+// nested BVH per mesh, common/Scene.cpp:9-23 + common/BVH.cpp:92-104) and flattens it: every
+// top-level mesh leaf is replaced by its mesh's subtree, whose exits continue at the node that
+// follows the leaf; a sphere is a leaf of the top level itself.
 void Scene::buildBVH() {
-    if (meshes.empty()) throw std::runtime_error("Scene::buildBVH: scene has no meshes");
-    std::vector<Object*> objects(meshes.begin(), meshes.end());
-    bvh_owner_ = std::make_shared<BVHAccel>(objects, 1, BVHAccel::SplitMethod::NAIVE);
+    if (objects.empty()) throw std::runtime_error("Scene::buildBVH: scene has no meshes");
+    std::vector<Object*> top_objects;
+    for (const ObjectRef& o : objects) top_objects.push_back(o.sphere ? (Object*)spheres[o.index] : (Object*)meshes[o.index]);
+    bvh_owner_ = std::make_shared<BVHAccel>(top_objects, 1, BVHAccel::SplitMethod::NAIVE);
     bvh = bvh_owner_.get();
     mesh_bvh_owner_.clear();
     mesh_bvhs.clear();
-    std::vector<int32_t> mesh_base(meshes.size());
-    int32_t base = 0;
-    for (size_t k = 0; k < meshes.size(); ++k) {
-        MeshTriangle* m = meshes[k];
+    for (MeshTriangle* m : meshes) {
         std::vector<Object*> tris(m->triangles.size());
         for (size_t i = 0; i < tris.size(); ++i) tris[i] = &m->triangles[i];
         mesh_bvh_owner_.push_back(std::make_shared<BVHAccel>(tris, 1, BVHAccel::SplitMethod::NAIVE));
         mesh_bvhs.push_back(mesh_bvh_owner_.back().get());
-        mesh_base[k] = base;
-        base += m->num_triangles;
+    }
+    // primitive ids count through the objects in Add order (a sphere is one primitive)
+    std::vector<int32_t> object_base(objects.size());
+    int32_t base = 0;
+    for (size_t k = 0; k < objects.size(); ++k) {
+        object_base[k] = base;
+        base += objects[k].sphere ? 1 : meshes[objects[k].index]->num_triangles;
     }
 
     // global index of every top-level node once the mesh subtrees are spliced in
@@ -69,7 +81,8 @@ void Scene::buildBVH() {
     int32_t cursor = 0;
     for (size_t t = 0; t < top.size(); ++t) {
         top_to_global[t] = cursor;
-        cursor += top[t].object >= 0 ? (int32_t)mesh_bvhs[top[t].object]->nodes.size() : 1;
+        const bool mesh_leaf = top[t].object >= 0 && !objects[top[t].object].sphere;
+        cursor += mesh_leaf ? (int32_t)mesh_bvhs[objects[top[t].object].index]->nodes.size() : 1;
     }
     top_to_global[top.size()] = cursor;
     const uint32_t num_nodes = (uint32_t)cursor, num_tris = (uint32_t)base;
@@ -99,7 +112,22 @@ void Scene::buildBVH() {
             write_node(g0, tn.bounds, top_to_global[tn.miss], -1, tn.area);
             continue;
         }
-        const int k = tn.object;
+        const int obj = tn.object;  // index into `objects` = material index
+        if (objects[obj].sphere) {
+            const Sphere* sp = spheres[objects[obj].index];
+            const int32_t rec = next_tri++;
+            float* r = fs->tris.data + 16ull * rec;
+            r[0] = sp->center.x; r[1] = sp->center.y; r[2] = sp->center.z; r[3] = 0.f;
+            r[4] = sp->radius; r[5] = sp->radius2; r[6] = 0.f; put_int(r + 7, obj);
+            r[8] = r[9] = r[10] = 0.f; put_int(r + 11, object_base[obj]);
+            r[12] = r[13] = r[14] = 0.f; put_int(r + 15, (int32_t)((uint32_t)obj | 0x80000000u));
+            float* w = fs->tri_v12.data + 8ull * rec;
+            for (int c = 0; c < 8; ++c) w[c] = 0.f;
+            fs->prim_of_tri[rec] = object_base[obj];
+            write_node(g0, tn.bounds, top_to_global[tn.miss], rec, tn.area);
+            continue;
+        }
+        const int k = objects[obj].index;
         const MeshTriangle* mesh = meshes[k];
         const std::vector<FlatNode>& mn = mesh_bvhs[k]->nodes;
         // The reference tests the mesh's bounding box (top-level leaf) and then
@@ -116,20 +144,20 @@ void Scene::buildBVH() {
                 const Triangle& T = mesh->triangles[n.object];
                 float* r = fs->tris.data + 16ull * tri;
                 r[0] = T.v0.x; r[1] = T.v0.y; r[2] = T.v0.z; r[3] = T.area;
-                r[4] = T.e1.x; r[5] = T.e1.y; r[6] = T.e1.z; put_int(r + 7, k);
-                r[8] = T.e2.x; r[9] = T.e2.y; r[10] = T.e2.z; put_int(r + 11, mesh_base[k] + n.object);
-                r[12] = T.normal.x; r[13] = T.normal.y; r[14] = T.normal.z; put_int(r + 15, k);
+                r[4] = T.e1.x; r[5] = T.e1.y; r[6] = T.e1.z; put_int(r + 7, obj);
+                r[8] = T.e2.x; r[9] = T.e2.y; r[10] = T.e2.z; put_int(r + 11, object_base[obj] + n.object);
+                r[12] = T.normal.x; r[13] = T.normal.y; r[14] = T.normal.z; put_int(r + 15, obj);
                 float* w = fs->tri_v12.data + 8ull * tri;
                 w[0] = T.v1.x; w[1] = T.v1.y; w[2] = T.v1.z; w[3] = 0.f;
                 w[4] = T.v2.x; w[5] = T.v2.y; w[6] = T.v2.z; w[7] = 0.f;
-                fs->prim_of_tri[tri] = mesh_base[k] + n.object;
+                fs->prim_of_tri[tri] = object_base[obj] + n.object;
             }
             write_node(g0 + (int32_t)i, n.bounds, g0 + n.miss, tri, n.area);
         }
     }
 
-    for (size_t k = 0; k < meshes.size(); ++k) {
-        const Material& m = meshes[k]->material;
+    for (size_t obj = 0; obj < objects.size(); ++obj) {
+        const Material& m = objects[obj].sphere ? spheres[objects[obj].index]->material : meshes[objects[obj].index]->material;
         hpt_material hm;
         std::memset(&hm, 0, sizeof hm);
         hm.type = m.type;
@@ -139,12 +167,13 @@ void Scene::buildBVH() {
         hm.roughness = m._roughness;
         hm.ior = m._ior;
         fs->materials.push_back(hm);
-        if (m.emitting()) {
+        if (!objects[obj].sphere && m.emitting()) {
+            const int k = objects[obj].index;
             hpt_light L;
             L.area = meshes[k]->area;
             L.root_area = mesh_bvhs[k]->rootArea();
             L.root_node = (uint32_t)fs->mesh_root[k];
-            L.material = (uint32_t)k;
+            L.material = (uint32_t)obj;
             fs->lights.push_back(L);
         }
     }

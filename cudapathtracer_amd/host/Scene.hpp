@@ -56,6 +56,16 @@ public:
 
     // takes shared ownership of the mesh
     void Add(MeshTriangle* mesh);
+    // a sphere (no counterpart in the reference, whose Scene::Add takes MeshTriangle* only); must not emit
+    void Add(Sphere* sphere);
+    std::vector<Sphere*> spheres;
+    // meshes and spheres in Add order: {false, index into meshes} / {true, index into spheres}.  Material
+    // indices and primitive ids of the flattened scene count through this list.
+    struct ObjectRef {
+        bool sphere;
+        int index;
+    };
+    std::vector<ObjectRef> objects;
     void buildBVH();
 
     enum BuiltinScene {
@@ -95,6 +105,7 @@ public:
 
 private:
     std::vector<std::shared_ptr<MeshTriangle>> mesh_owner_;
+    std::vector<std::shared_ptr<Sphere>> sphere_owner_;
     std::shared_ptr<BVHAccel> bvh_owner_;
     std::vector<std::shared_ptr<BVHAccel>> mesh_bvh_owner_;
     std::shared_ptr<FlatScene> flat_;

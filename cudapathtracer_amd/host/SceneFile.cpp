@@ -13,6 +13,7 @@
 //   material   <id> glass   [roughness r] [ior n] [albedo r g b]
 //   mesh       <file.obj> <material id> [translate x y z] [rotate x y z] [scale x y z | scale s]
 //   heightfield <n> <material id>              the built-in n x n displaced height field
+//   sphere     <x> <y> <z> <radius> <material id>
 //
 // Unset material parameters keep the defaults of the reference's Material (common/Material.hpp:137-142).
 // Meshes are added in file order (= Scene::Add order = primitive id order).
@@ -115,6 +116,13 @@ Scene Scene::LoadSceneFile(const std::string& path, int maxDepth) {
             }
             const std::string full = !obj.empty() && obj[0] == '/' ? obj : dir + obj;
             scene.Add(new MeshTriangle(full, materials[id], t));
+            ++meshes;
+        } else if (key == "sphere") {
+            float v[4];
+            std::string id;
+            if (!read_floats(in, v, 4) || !(in >> id)) bad(path, lineno, "sphere <x> <y> <z> <radius> <material id>");
+            if (!materials.count(id)) bad(path, lineno, "material '" + id + "' has not been defined");
+            scene.Add(new Sphere(Vec3(v[0], v[1], v[2]), v[3], materials[id]));
             ++meshes;
         } else if (key == "heightfield") {
             int n = 0;

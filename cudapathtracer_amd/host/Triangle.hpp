@@ -35,6 +35,22 @@ public:
     Bounds3 getBounds() const override { return Union(Bounds3(v0, v1), v2); }
 };
 
+// Sphere: the primitive of common/Sphere.hpp:13-101, which the reference keeps commented out
+// (north_star names it).  Members as there; an object of the top-level BVH like a mesh.  Spheres
+// do not emit (Scene::sampleLight only knows meshes).
+class Sphere : public Object {
+public:
+    Vec3 center;
+    float radius = 0.f, radius2 = 0.f;
+    Material material;
+    Sphere(const Vec3& c, float r, const Material& mt) : center(c), radius(r), radius2(r * r), material(mt) {
+        area = 4 * 3.1415926535897932384626422832795028841971f * r * r;
+    }
+    Bounds3 getBounds() const override {
+        return Bounds3(Vec3(center.x - radius, center.y - radius, center.z - radius), Vec3(center.x + radius, center.y + radius, center.z + radius));
+    }
+};
+
 // Translation, rotation (degrees about x, then y, then z) and scale of a mesh, composed as
 // Math::buildTransformationMatrix does (common/MathUtils.hpp:109-116): M = T * Rx * Ry * Rz * S.
 // The reference declares that helper and never calls it (a MeshTriangle is the OBJ's vertices

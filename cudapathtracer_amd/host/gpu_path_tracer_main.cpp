@@ -11,6 +11,7 @@
 //   HPT_DEVICE               GPU index (default 0)
 //   HPT_GPUS=N               shard the samples over GPUs 0..N-1 (one RCCL reduce sums the accumulators)
 //   HPT_DEVICES=0,1,3        the same over the GPUs listed (an index may repeat: rehearsal on one GPU)
+//   HPT_INTEGRATOR=rr,regularize   Russian roulette / path regularisation as the reference writes them (off there)
 //   HPT_SCENE                bunny | glass | heightfield:<n> | file:<scene file> instead of the reference's Cornell box
 #include <cstdlib>
 #include <iostream>
@@ -59,6 +60,11 @@ int main(int argc, char** argv) {
             }
         }
         if (r.devices.size() > 1) std::cout << "HIP #GPUs: " << r.devices.size() << std::endl;
+        if (const char* i = getenv("HPT_INTEGRATOR")) {  // "rr", "regularize" or "rr,regularize"
+            const std::string v = i;
+            if (v.find("rr") != std::string::npos) r.integrator |= HPT_INTEGRATOR_RUSSIAN_ROULETTE;
+            if (v.find("regularize") != std::string::npos) r.integrator |= HPT_INTEGRATOR_REGULARIZE;
+        }
         if (const char* t = getenv("HPT_TRAVERSAL")) r.traversal = std::string(t) == "culled" ? HPT_TRAVERSAL_CULLED : HPT_TRAVERSAL_REFERENCE;
 
         r.PrepareRender(scene);

@@ -137,6 +137,11 @@ int hpt_host_scene_add_triangles(hpt_host_scene* s, const float* verts9, int num
     })
 }
 
+int hpt_host_scene_add_sphere(hpt_host_scene* s, const float center[3], float radius, const hpt_material* material) {
+    if (!s || !center || !material) return fail("null argument");
+    GUARD(s->scene.Add(new Sphere(Vec3(center[0], center[1], center[2]), radius, to_material(material))))
+}
+
 int hpt_host_scene_build(hpt_host_scene* s) {
     if (!s) return fail("scene is null");
     GUARD(s->scene.buildBVH())

@@ -81,6 +81,10 @@ typedef struct {
  *                                 e2.xyz, bits(prim id) | normal.xyz, bits(mesh index)
  *   with e1, e2, normal, area precomputed as common/Triangle.hpp:52-59 does and
  *   prim id = mesh base + triangle index within the mesh (Scene::Add order).
+ *   A record whose word 15 has bit 31 set is a SPHERE (common/Sphere.hpp, commented out in the
+ *   reference; north_star names the primitive):  center.xyz, 0 | radius, radius^2, 0, bits(material)
+ *   | 0, 0, 0, bits(prim id) | 0, 0, 0, bits(mesh | 0x80000000); its leaf's box is center -+ radius.
+ *   Spheres do not emit.  Scenes with spheres use the two-child-record traversal whatever their size.
  * tri_v12: v1.xyz, 0, v2.xyz, 0 per triangle (Triangle::Sample needs v1, v2
  *   themselves, common/Triangle.hpp:75-82).
  * node_area: BVHBuildNode::area per node (common/BVH.cpp:111,121,164), used by
@@ -139,6 +143,20 @@ int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* scene);
  *   wavefront_capacity: paths in flight per streamed batch (default 1<<24: 2 GiB of path state)   */
 int hpt_set_seed(hpt_ctx* ctx, uint32_t seed);
 int hpt_set_wavefront_capacity(hpt_ctx* ctx, uint64_t paths);
+
+/* The two steps of Scene::TracePath that the reference switches off at compile time
+ * (`const bool pathRegularization = false, enableRR = false`, common/Scene.hpp:141-142), as run-time
+ * options; takes effect at the next hpt_render.  Restated as written there (parity unpinned: no
+ * input reaches them in the reference):
+ *   HPT_INTEGRATOR_RUSSIAN_ROULETTE  :252-264 -- one more random draw per bounce; from the third
+ *     bounce on, throughput /= RussianRoulette (0.8) unless the draw falls below 1 - RussianRoulette.
+ *     As in the reference, such a bounce only goes without the compensation: the `break` there
+ *     leaves the function's while(true) wrapper, it does not end the path.
+ *   HPT_INTEGRATOR_REGULARIZE        :186-189 -- once a path has left a non-specular surface, materials
+ *     are evaluated after Material::regularize() (common/Material.hpp:164-171). */
+#define HPT_INTEGRATOR_RUSSIAN_ROULETTE 1u
+#define HPT_INTEGRATOR_REGULARIZE 2u
+int hpt_set_integrator(hpt_ctx* ctx, uint32_t flags);
 
 /* Traversal order for scenes of more than 64 triangles; takes effect at the next hpt_scene_upload.
  *   HPT_TRAVERSAL_REFERENCE (default): exactly the boxes and triangles BVHAccel::getIntersection

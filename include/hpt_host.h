@@ -38,6 +38,9 @@ int hpt_host_scene_info(const hpt_host_scene* s, int* width, int* height, char* 
  * Math::buildTransformationMatrix (common/MathUtils.hpp:109-116), which the reference never calls. */
 int hpt_host_scene_add_obj_transformed(hpt_host_scene* s, const char* obj_path, const hpt_material* material, const float translation[3],
                                        const float rotation_deg[3], const float scale[3]);
+/* Scene::Add(Sphere*): a sphere as an object of the top-level BVH (common/Sphere.hpp is commented out
+ * in the reference; no counterpart in its Scene).  The material must not emit. */
+int hpt_host_scene_add_sphere(hpt_host_scene* s, const float center[3], float radius, const hpt_material* material);
 int hpt_host_scene_create(int width, int height, const float cam_pos[3], double fov_deg, int max_depth,
                           hpt_host_scene** out);
 /* Scene::Add(new MeshTriangle(...)) (common/Scene.hpp:47-56, common/Triangle.cpp:5-61) */

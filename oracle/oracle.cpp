@@ -182,7 +182,7 @@ static inline unsigned int utilhash(unsigned int a) {  // MathUtils.hpp:53-61
     return a;
 }
 
-enum Slot { kSlotLightPick = 0, kSlotTriPick = 1, kSlotTriX = 2, kSlotTriY = 3, kSlotBsdf0 = 4, kSlotBsdf1 = 5, kSlotBsdf2 = 6 };
+enum Slot { kSlotLightPick = 0, kSlotTriPick = 1, kSlotTriX = 2, kSlotTriY = 3, kSlotBsdf0 = 4, kSlotBsdf1 = 5, kSlotBsdf2 = 6, kSlotRoulette = 7 };
 
 struct Rng {
     int mode = ORC_RNG_MT;
@@ -324,6 +324,13 @@ struct Material {  // Material.hpp:130-384
     bool emitting() const { return dot(_emission, _emission) > 0.0f; }                        // :144-146
     float alpha() const { return std::sqrt(_roughness); }                                     // :151-153
     bool hasSpecular() const { return (type == MetallicWorkflow && alpha() < 1e-3f) || type == Glass; }  // :155-162
+    void regularize() {                                                                        // :164-171
+        float alpha_x = alpha();
+        if (alpha_x < 0.3f) {
+            alpha_x = gmin(gmax(2 * alpha_x, 0.1f), 0.3f);  // glm::clamp = min(max(x, lo), hi)
+            _roughness = alpha_x * alpha_x;
+        }
+    }
 
     // :186-219.  The two Lambert draws are *arguments of one call* in the
     // reference (:189); g++ evaluates them right to left, so the stream's first
@@ -557,6 +564,58 @@ struct Mesh {
     Material material;
 };
 
+// common/MathUtils.hpp:86-100.  The unqualified `sqrt(discr)` there resolves to the C library's
+// sqrt(double); sums and products with it and with the double literal -0.5 are evaluated in double
+// and narrowed on assignment (checked against the compiled reference, 20 006 coefficient triples).
+static inline bool solveQuadratic(const float& a, const float& b, const float& c, float& x0, float& x1) {
+    float discr = b * b - 4 * a * c;
+    if (discr < 0)
+        return false;
+    else if (discr == 0)
+        x0 = x1 = -0.5 * b / a;
+    else {
+        float q = (b > 0) ? -0.5 * (b + std::sqrt((double)discr)) : -0.5 * (b - std::sqrt((double)discr));
+        x0 = q / a;
+        x1 = c / q;
+    }
+    if (x0 > x1) std::swap(x0, x1);
+    return true;
+}
+
+// common/Sphere.hpp:13-101 -- the whole file is commented out in the reference and no scene can
+// hold a sphere (Scene::Add takes MeshTriangle*), so this restates the commented text:
+// getIntersection (:49-69) and getBounds (:81-84).  Parity unpinned except for solveQuadratic,
+// which is live code.  A sphere is an object of the top-level BVH like a mesh; spheres do not emit.
+struct Sphere {
+    V3 center;
+    float radius = 0.f, radius2 = 0.f, area = 0.f;
+    Material material;
+    int prim = -1;
+    Sphere(V3 c, float r, const Material& mt) : center(c), radius(r), radius2(r * r), area(4 * kPi * r * r), material(mt) {}
+    Bounds3 getBounds() const {
+        return Bounds3(mk(center.x - radius, center.y - radius, center.z - radius), mk(center.x + radius, center.y + radius, center.z + radius));
+    }
+    Intersection getIntersection(const Ray& ray) const {
+        Intersection result;
+        V3 L = ray.origin - center;
+        float a = dot(ray.direction, ray.direction);
+        float b = 2 * dot(ray.direction, L);
+        float c = dot(L, L) - radius2;
+        float t0, t1;
+        if (!solveQuadratic(a, b, c, t0, t1)) return result;
+        if (t0 < 0) t0 = t1;
+        if (t0 < 0) return result;
+        result.happened = true;
+        result.coords = ray.origin + ray.direction * t0;
+        result.normal = normalize(result.coords - center);
+        result.m = &material;
+        result.distance = t0;
+        result.triangleArea = area;
+        result.prim = prim;
+        return result;
+    }
+};
+
 // ----------------------------------------------------------------------------
 // common/BVH.hpp, common/BVH.cpp
 // ----------------------------------------------------------------------------
@@ -568,6 +627,7 @@ struct Node {
     int mesh = -1;           // top level leaf: mesh index
     Bvh* meshBvhRoot = nullptr;
     const Triangle* triangle = nullptr;
+    const Sphere* sphere = nullptr;  // top level leaf: a sphere
     float area = 0.f;
     Node* nextIfHit = nullptr;
     Node* nextIfMiss = nullptr;
@@ -579,6 +639,7 @@ struct Node {
 struct Obj {
     int mesh = -1;                       // >= 0: a MeshTriangle
     const Triangle* triangle = nullptr;  // else: a Triangle
+    const Sphere* sphere = nullptr;      // or a Sphere
 };
 
 struct Scene;
@@ -600,16 +661,31 @@ struct Scene {
     double fov = 40;
     V3 camPos = mk(0.f);
     std::vector<Mesh*> meshes;
+    std::vector<Sphere*> spheres;
+    std::vector<Obj> objects;  // meshes and spheres in Scene::Add order
     Bvh* bvh = nullptr;
     std::vector<Bvh*> mesh_bvhs;
     std::vector<int> mesh_base;
     float sumLightArea = 0.f, sumLightPower = 0.f;
     int num_lights = 0;
+    // the integrator's switches, compile-time `false` in the reference (Scene.hpp:141-142)
+    bool pathRegularization = false, enableRR = false;
+    float RussianRoulette = 0.8f;  // Scene.hpp:30
     ~Scene() {
         delete bvh;
         for (Mesh* m : meshes) delete m;
+        for (Sphere* sp : spheres) delete sp;
+    }
+    void Add(Sphere* sphere) {
+        Obj o;
+        o.sphere = sphere;
+        objects.push_back(o);
+        spheres.push_back(sphere);
     }
     void Add(Mesh* mesh) {  // Scene.hpp:47-56
+        Obj mo;
+        mo.mesh = (int)meshes.size();
+        objects.push_back(mo);
         meshes.push_back(mesh);
         if (mesh->material.emitting()) {
             sumLightArea += mesh->area;
@@ -618,16 +694,16 @@ struct Scene {
         }
     }
     void buildBVH() {  // Scene.cpp:9-23
-        std::vector<Obj> objects;
-        for (size_t i = 0; i < meshes.size(); ++i) {
-            Obj o;
-            o.mesh = (int)i;
-            objects.push_back(o);
-        }
-        mesh_base.clear();
+        // primitive ids count through the objects in Add order (a sphere is one primitive)
+        mesh_base.assign(meshes.size(), 0);
         int base = 0;
-        for (Mesh* m : meshes) {
-            mesh_base.push_back(base);
+        for (const Obj& o : objects) {
+            if (o.sphere) {
+                const_cast<Sphere*>(o.sphere)->prim = base++;
+                continue;
+            }
+            Mesh* m = meshes[o.mesh];
+            mesh_base[o.mesh] = base;
             for (size_t k = 0; k < m->triangles.size(); ++k) {
                 m->triangles[k].prim = base + (int)k;
                 m->triangles[k].material = &m->material;
@@ -636,10 +712,11 @@ struct Scene {
         }
         delete bvh;
         mesh_bvhs.assign(meshes.size(), nullptr);
-        bvh = new Bvh(*this, objects, mesh_bvhs);
+        std::vector<Obj> top(objects);
+        bvh = new Bvh(*this, top, mesh_bvhs);
     }
-    Bounds3 boundsOf(const Obj& o) const { return o.mesh >= 0 ? meshes[o.mesh]->bounding_box : o.triangle->getBounds(); }
-    float areaOf(const Obj& o) const { return o.mesh >= 0 ? meshes[o.mesh]->area : o.triangle->area; }
+    Bounds3 boundsOf(const Obj& o) const { return o.sphere ? o.sphere->getBounds() : o.mesh >= 0 ? meshes[o.mesh]->bounding_box : o.triangle->getBounds(); }
+    float areaOf(const Obj& o) const { return o.sphere ? o.sphere->area : o.mesh >= 0 ? meshes[o.mesh]->area : o.triangle->area; }
 };
 
 static void preorder(Node* n, std::vector<Node*>& out) {  // BVH.cpp:8-15
@@ -669,7 +746,9 @@ Node* Bvh::recursiveBuild(const Scene& scene, std::vector<Obj>& objects, std::ve
     Node* node = new Node();
     if (objects.size() == 1) {
         node->bounds = scene.boundsOf(objects[0]);
-        if (objects[0].mesh >= 0) {
+        if (objects[0].sphere) {
+            node->sphere = objects[0].sphere;
+        } else if (objects[0].mesh >= 0) {
             node->mesh = objects[0].mesh;
             Mesh* mesh = scene.meshes[objects[0].mesh];
             std::vector<Obj> triangles(mesh->triangles.size());
@@ -720,6 +799,7 @@ Intersection Bvh::getIntersection(const Ray& ray, Counters& cnt) const {  // BVH
             if (!current->left && !current->right) {
                 Intersection hit;
                 if (current->mesh >= 0) hit = current->meshBvhRoot->getIntersection(ray, cnt);
+                else if (current->sphere) { ++cnt.tri; hit = current->sphere->getIntersection(ray); }
                 else { ++cnt.tri; hit = current->triangle->getIntersection(ray); }
                 if (hit.happened) {
                     if (ray.shadowTest) {
@@ -797,7 +877,7 @@ static Intersection sceneIntersect(const Scene& sc, const Ray& ray, Tally& tl) {
     return sc.bvh->getIntersection(ray, tl.cnt);
 }
 
-// Scene.hpp:122-272 (pathRegularization = enableRR = false)
+// Scene.hpp:122-272 (pathRegularization and enableRR are compile-time false there; switches of Scene here)
 static void TracePath(const Scene& sc, const Trig& tg, PathSegment& path, Intersection& intersec, Tally& tl) {
     V3& accRadiance = path.radiance;
     V3& throughput = path.throughput;
@@ -808,7 +888,8 @@ static void TracePath(const Scene& sc, const Trig& tg, PathSegment& path, Inters
             path.remainingBounces = 0;
             break;
         }
-        const Material& material = *intersec.m;
+        Material material = *intersec.m;  // the reference's Intersection holds the Material by value
+        if (sc.pathRegularization && path.anyNonSpecularBounces) material.regularize();  // :186-189
         if (material.emitting()) {  // :164-184
             if (path.depth == 0 || path.specularBounce) {
                 accRadiance = accRadiance + throughput * material._emission;
@@ -859,6 +940,16 @@ static void TracePath(const Scene& sc, const Trig& tg, PathSegment& path, Inters
         float cos_theta = absDot(intersec.normal, wi);
         throughput = throughput * (bsdf * cos_theta / path.bsdfSamplePdf);
         ray = Ray(p + wi * kEpsilon5, wi);
+        // :252-264, as written: the `break` only leaves the reference's while(true) wrapper, it does
+        // not end the path -- a "killed" bounce merely goes without the 1 / (1 - q) compensation
+        if (sc.enableRR) {
+            float rrProb = path.rng.draw(d, kSlotRoulette);
+            if (path.depth > 1) {
+                float q = 1 - sc.RussianRoulette;
+                if (rrProb < q) break;
+                throughput = throughput / (1.f - q);
+            }
+        }
     } while (false);
 
     path.depth++;  // :268-271
@@ -1012,6 +1103,21 @@ int orc_scene_add_triangles(orc_scene* s, const float* verts9, int num_tris, con
     s->sc.Add(makeMesh(fv, from_c(m)));
     return (int)s->sc.meshes.size() - 1;
 }
+int orc_scene_add_sphere(orc_scene* s, const float center[3], float radius, const orc_material* m) {
+    s->sc.Add(new Sphere(mk(center[0], center[1], center[2]), radius, from_c(m)));
+    return (int)s->sc.spheres.size() - 1;
+}
+void orc_scene_set_integrator(orc_scene* s, int russian_roulette, int path_regularization) {
+    s->sc.enableRR = russian_roulette != 0;
+    s->sc.pathRegularization = path_regularization != 0;
+}
+float orc_material_regularize(float roughness) {
+    Material m;
+    m._roughness = roughness;
+    m.regularize();
+    return m._roughness;
+}
+int orc_solve_quadratic(float a, float b, float c, float* x0, float* x1) { return solveQuadratic(a, b, c, *x0, *x1) ? 1 : 0; }
 int orc_scene_build(orc_scene* s) {
     s->sc.buildBVH();
     return 0;
@@ -1101,7 +1207,11 @@ int orc_bvh_dump(const orc_scene* s, int mesh, float* bounds6, int* payload, flo
         bounds6[6 * i + 3] = n->bounds.pMax.x; bounds6[6 * i + 4] = n->bounds.pMax.y; bounds6[6 * i + 5] = n->bounds.pMax.z;
         bool leaf = !n->left && !n->right;
         if (!leaf) payload[i] = -1;
-        else if (n->mesh >= 0) payload[i] = n->mesh;
+        else if (n->mesh >= 0 || n->sphere) {  // top level: the object's position in Scene::Add order
+            payload[i] = -1;
+            for (size_t k = 0; k < s->sc.objects.size(); ++k)
+                if ((n->sphere && s->sc.objects[k].sphere == n->sphere) || (!n->sphere && s->sc.objects[k].mesh == n->mesh && !s->sc.objects[k].sphere)) payload[i] = (int)k;
+        }
         else payload[i] = (int)(n->triangle - s->sc.meshes[mesh]->triangles.data());
         area[i] = n->area;
         miss_rank[i] = n->nextIfMiss ? rank_of.at(n->nextIfMiss) : (int)nodes.size();

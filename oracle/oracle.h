@@ -52,6 +52,14 @@ orc_scene* orc_scene_create_cornell(const char* models_dir, int width, int heigh
 int orc_scene_add_obj(orc_scene*, const char* obj_path, const orc_material*);
 /* triangle soup: 9 floats per triangle (v0 v1 v2) */
 int orc_scene_add_triangles(orc_scene*, const float* verts9, int num_tris, const orc_material*);
+/* a sphere as an object of the top-level BVH (common/Sphere.hpp, commented out in the reference) */
+int orc_scene_add_sphere(orc_scene*, const float center[3], float radius, const orc_material*);
+/* enableRR / pathRegularization of Scene::TracePath (common/Scene.hpp:141-142; compile-time false there) */
+void orc_scene_set_integrator(orc_scene*, int russian_roulette, int path_regularization);
+/* solveQuadratic (common/MathUtils.hpp:86-100) */
+int orc_solve_quadratic(float a, float b, float c, float* x0, float* x1);
+/* Material::regularize (common/Material.hpp:164-171): roughness in, roughness out */
+float orc_material_regularize(float roughness);
 int orc_scene_build(orc_scene*);
 void orc_scene_set_resolution(orc_scene*, int width, int height);
 

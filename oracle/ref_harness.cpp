@@ -367,6 +367,17 @@ void ref_sample_light(long n, int iter0, int index, float* out11, float* u_out) 
 
 float ref_power_heuristic(float f, float g) { return Math::powerHeuristic(f, g); }
 
+// solveQuadratic (common/MathUtils.hpp:86-100): the live half of the commented-out Sphere
+int ref_solve_quadratic(float a, float b, float c, float* x0, float* x1) { return solveQuadratic(a, b, c, *x0, *x1) ? 1 : 0; }
+
+// Material::regularize (common/Material.hpp:164-171): roughness in, roughness out
+float ref_material_regularize(float roughness) {
+    Material m;
+    m._roughness = roughness;
+    m.regularize();
+    return m._roughness;
+}
+
 // SavePPM tone curve of one channel value (Utility.cpp:16)
 int ref_tonemap(float v) { return (unsigned char)(255 * glm::pow(clamp(0, 1, v), 0.6f)); }
 

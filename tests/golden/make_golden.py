@@ -142,8 +142,27 @@ def large_scenes(R):
     R.cornell(5)
 
 
+def extras(R):
+    """solveQuadratic (common/MathUtils.hpp:86-100, the live half of the commented-out Sphere) and
+    Material::regularize (common/Material.hpp:164-171) of the compiled reference."""
+    import ctypes as C
+    rs = np.random.RandomState(5)
+    abc = np.concatenate([np.array([(1, 0, 0), (1, 2, 1), (1, -2, 1), (0, 1, 1), (2, 4, 2), (1, 0, -1), (1, 1e-3, -1e6), (1, -3e4, 2)], np.float32),
+                          (rs.randn(4000, 3) * [2, 20, 200]).astype(np.float32)])
+    out = np.zeros((len(abc), 3), np.float32)
+    for i, (a, b, c) in enumerate(abc):
+        x0, x1 = C.c_float(), C.c_float()
+        ok = R.lib.ref_solve_quadratic(float(a), float(b), float(c), C.byref(x0), C.byref(x1))
+        out[i] = (ok, x0.value if ok else 0, x1.value if ok else 0)
+    rough = np.concatenate([np.linspace(0, 1.2, 1201), [0.005, 0.0025, 0.09, 0.0225]]).astype(np.float32)
+    reg = np.array([R.lib.ref_material_regularize(float(v)) for v in rough], np.float32)
+    np.savez_compressed(os.path.join(HERE, "extras.npz"), quad_abc=abc, quad_out=out, rough_in=rough, rough_out=reg)
+
+
 def main():
     R = Ref().cornell(5)
+    if sys.argv[1:] == ["extras"]:
+        return extras(R)
     if sys.argv[1:] == ["glass"]:
         return glass(R)
     if sys.argv[1:] == ["scenes"]:
@@ -272,6 +291,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "cornell_shading.npz"), **sh)
     glass(R)
     large_scenes(R)
+    extras(R)
     for f in sorted(os.listdir(HERE)):
         print("%8d  %s" % (os.path.getsize(os.path.join(HERE, f)), f))
 

@@ -61,6 +61,11 @@ class Oracle:
         L.orc_scene_add_obj.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(Material)]
         L.orc_scene_add_triangles.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Material)]
         L.orc_scene_build.argtypes = [C.c_void_p]
+        L.orc_scene_add_sphere.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.POINTER(Material)]
+        L.orc_scene_set_integrator.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_solve_quadratic.argtypes = [C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.orc_material_regularize.restype = C.c_float
+        L.orc_material_regularize.argtypes = [C.c_float]
         L.orc_scene_set_resolution.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.orc_scene_info.argtypes = [C.c_void_p] + [C.c_void_p] * 8
         L.orc_mesh_info.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4
@@ -173,6 +178,14 @@ class OracleScene:
         v = _f32(verts).reshape(-1, 9)
         return self.lib.orc_scene_add_triangles(self.h, _p(v), len(v), C.byref(mat))
 
+    def add_sphere(self, center, radius, mat):
+        c = _f32(center)
+        return self.lib.orc_scene_add_sphere(self.h, _p(c), float(radius), C.byref(mat))
+
+    def set_integrator(self, russian_roulette=False, path_regularization=False):
+        self.lib.orc_scene_set_integrator(self.h, int(russian_roulette), int(path_regularization))
+        return self
+
     def build(self):
         self.lib.orc_scene_build(self.h)
         return self
@@ -280,6 +293,9 @@ class Ref:
         L.ref_power_heuristic.restype = C.c_float
         L.ref_power_heuristic.argtypes = [C.c_float, C.c_float]
         L.ref_tonemap.argtypes = [C.c_float]
+        L.ref_solve_quadratic.argtypes = [C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.ref_material_regularize.restype = C.c_float
+        L.ref_material_regularize.argtypes = [C.c_float]
 
     def cornell(self, max_depth=5, root=ROOT):
         rc = self.lib.ref_scene_cornell(root.encode(), max_depth)

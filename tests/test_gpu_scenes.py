@@ -407,3 +407,101 @@ def test_wave_scheduler_and_lockstep_kernels_agree(hp, oracle, gpu_ctx, monkeypa
         st = gpu_ctx.stats()
         assert (st["closest_queries"], st["shadow_queries"], st["paths"]) == (ost["closest_queries"], ost["shadow_queries"], w * h * spp)
         assert np.array_equal(got.view(np.int32), oracle.resolve(want_acc, spp).view(np.int32)), (mode, block)
+
+
+def _sphere_scene(hp, oracle, w, h, depth, big=False):
+    """Cornell shell + the short box mesh (or the bunny) + a near-mirror metal sphere, a glass sphere and a
+    Lambertian sphere, in one top-level BVH; the same objects in the oracle."""
+    from cudapathtracer_amd import scenes
+    shell = scenes.cornell_shell_triangles()
+    box = scenes.read_obj_triangles(os.path.join(scenes.DEFAULT_MODELS_DIR, "cornellbox", "shortbox.obj"))
+    extra = ("bunny", scenes.bunny_triangles(), scenes.WHITE) if big else ("shortbox", box, scenes.WHITE)
+    spheres = [((420, 90, 330), 90.0, dict(type=1, albedo=(.7, .5, .2), metallic=1.0, roughness=0.01)),
+               ((150, 330, 250), 70.0, dict(type=2, roughness=0.1, ior=1.5)),
+               ((300, 60, 120), 60.0, dict(type=0, albedo=(.3, .4, .8)))]
+    sc = hp.Scene(w, h, camPos=scenes.CORNELL_CAM, fov=40.0, maxDepth=depth)
+    osc = oracle.scene(w, h, scenes.CORNELL_CAM, 40.0)
+    order = [shell[0], spheres[0], shell[1], shell[2], spheres[1], extra, shell[3], spheres[2]]
+    for item in order:
+        if len(item) == 3 and isinstance(item[0], str):
+            sc.Add(item[1], hp.Material(**item[2]))
+            osc.add_triangles(item[1], Material.make(**item[2]))
+        else:
+            sc.AddSphere(item[0], item[1], hp.Material(**item[2]))
+            osc.add_sphere(item[0], item[1], Material.make(**item[2]))
+    return sc.buildBVH(), osc.build()
+
+
+@pytest.mark.parametrize("big", [False, True])
+def test_spheres(hp, oracle, gpu_ctx, big):
+    """Sphere primitives (common/Sphere.hpp is commented out in the reference: the oracle restates the
+    commented text, parity unpinned except for solveQuadratic) among meshes: hits on closest and
+    any-hit batches, images and ray counters in both modes, bit-exact against the oracle -- with the
+    two-child records in LDS (24 primitives) and through L1/L2 under the wave scheduler (bunny)."""
+    from cudapathtracer_amd import scenes
+    w, h, depth, spp = 56, 44, 8, 3
+    sc, osc = _sphere_scene(hp, oracle, w, h, depth, big)
+    gpu_ctx.upload(sc)
+    assert gpu_ctx.stats()["variant"] == (5 if big else 6)   # never a marking variant: those test triangles only
+    f = sc.flat_arrays()
+    sphere_prims = set(int(p) for p in f["prim_of_tri"][(f["tris"][:, 15].view(np.uint32) >> 31) == 1])
+    o, d = primary_rays(160, 160, scenes.CORNELL_CAM, osc.info()["cam_scale"])
+    hit = _same_hits(gpu_ctx, osc, o, d)
+    assert all((hit == p).mean() > 0.005 for p in sphere_prims), "every sphere is in view"
+    _same_hits(gpu_ctx, osc, *random_rays(1 << 16, 81))
+    # rays that start inside the spheres (far root) and any-hit queries through them
+    rs = np.random.RandomState(82)
+    inside = (np.array([420, 90, 330]) + (rs.rand(4096, 3) - 0.5) * 80).astype(np.float32)
+    dirs = rs.randn(4096, 3)
+    dirs = (dirs / np.linalg.norm(dirs, axis=1, keepdims=True)).astype(np.float32)
+    got = _same_hits(gpu_ctx, osc, inside, dirs)
+    assert (got == min(sphere_prims)).mean() > 0.5   # (the bunny reaches into the metal sphere)
+    _same_occlusion(gpu_ctx, osc, *_shadow_batch(1 << 15, 83))
+    want_acc, ost = osc.render(RNG_PHILOX, TRIG_PORTABLE, depth, spp, fixed=True)
+    for mode in (1, 2):
+        gpu_ctx.stats_reset()
+        gpu_ctx.accum_clear()
+        gpu_ctx.render(mode, 256, depth, 0, spp)
+        got = gpu_ctx.resolve(spp)
+        st = gpu_ctx.stats()
+        assert (st["closest_queries"], st["shadow_queries"]) == (ost["closest_queries"], ost["shadow_queries"])
+        assert np.array_equal(got.view(np.int32), oracle.resolve(want_acc, spp).view(np.int32)), "mode %d" % mode
+
+
+@pytest.mark.parametrize("scene", ["glass_cornell", "bunny_metal"])
+@pytest.mark.parametrize("rr,reg", [(True, False), (False, True), (True, True)])
+def test_russian_roulette_and_path_regularisation(hp, oracle, gpu_ctx, scene, rr, reg):
+    """The two steps of Scene::TracePath the reference switches off at compile time
+    (common/Scene.hpp:141-142, :186-189, :252-264), as run-time options: images and counters bit-exact
+    against the oracle's restatement in both modes, and different from the default integrator's."""
+    from cudapathtracer_amd import scenes
+    if scene == "glass_cornell":
+        parts = scenes.glass_cornell_parts()
+        w, h, depth, spp = 48, 40, 12, 4
+    else:
+        parts = scenes.cornell_shell_triangles() + [("bunny", scenes.bunny_triangles(), scenes.METAL)]
+        w, h, depth, spp = 40, 32, 8, 2
+    sc = scenes._assemble(parts, w, h, depth)
+    osc = _oracle_scene(oracle, parts, w, h)
+    plain, _ = osc.render(RNG_PHILOX, TRIG_PORTABLE, depth, spp, fixed=True)
+    osc.set_integrator(rr, reg)
+    want_acc, ost = osc.render(RNG_PHILOX, TRIG_PORTABLE, depth, spp, fixed=True)
+    assert not np.array_equal(plain, want_acc)
+    gpu_ctx.upload(sc)
+    gpu_ctx.set_integrator(rr, reg)
+    try:
+        for mode in (1, 2):
+            gpu_ctx.stats_reset()
+            gpu_ctx.accum_clear()
+            gpu_ctx.render(mode, 256, depth, 0, spp)
+            got = gpu_ctx.resolve(spp)
+            st = gpu_ctx.stats()
+            assert (st["closest_queries"], st["shadow_queries"]) == (ost["closest_queries"], ost["shadow_queries"])
+            assert np.array_equal(got.view(np.int32), oracle.resolve(want_acc, spp).view(np.int32)), "mode %d" % mode
+    finally:
+        gpu_ctx.set_integrator(False, False)
+    gpu_ctx.accum_clear()
+    gpu_ctx.render(1, 256, depth, 0, spp)
+    assert np.array_equal(gpu_ctx.resolve(spp).view(np.int32), oracle.resolve(plain, spp).view(np.int32))
+    with pytest.raises(hp.HptError):
+        hp.api._ck(gpu_ctx._L.hpt_set_integrator(gpu_ctx._h, 8))   # an unknown flag

@@ -473,3 +473,42 @@ mesh {m}/light.obj light
         (tmp_path / "bad.scene").write_text(bad)
         with pytest.raises(hp.HptError, match=msg):
             hp.Scene.CreateNamedScene("file:" + str(tmp_path / "bad.scene"), 3)
+
+
+def test_sphere_in_the_flattened_scene(hp, oracle):
+    """Scene::Add(Sphere*): the sphere is a leaf of the top-level BVH (box = center -+ radius), its
+    record carries the sphere bit, material indices and primitive ids count through the objects in
+    Add order -- and the host BVH equals the oracle's over the same objects."""
+    from cudapathtracer_amd import scenes
+    from orclib import Material as OMat
+    shell = scenes.cornell_shell_triangles()
+    sc = hp.Scene(32, 32, camPos=scenes.CORNELL_CAM)
+    osc = oracle.scene(32, 32, scenes.CORNELL_CAM, 40.0)
+    metal = dict(type=1, albedo=(.7, .5, .2), metallic=1.0, roughness=0.01)
+    glass = dict(type=2, roughness=0.1, ior=1.5)
+    sc.Add(shell[0][1], hp.Material(**shell[0][2])); osc.add_triangles(shell[0][1], OMat.make(**shell[0][2]))
+    sc.AddSphere((200, 150, 300), 80.0, hp.Material(**metal)); osc.add_sphere((200, 150, 300), 80.0, OMat.make(**metal))
+    sc.Add(shell[3][1], hp.Material(**shell[3][2])); osc.add_triangles(shell[3][1], OMat.make(**shell[3][2]))
+    sc.AddSphere((400, 100, 200), 50.0, hp.Material(**glass)); osc.add_sphere((400, 100, 200), 50.0, OMat.make(**glass))
+    sc.buildBVH(); osc.build()
+    f = sc.flat_arrays()
+    w15 = f["tris"][:, 15].view(np.uint32)
+    is_sphere = (w15 >> 31) == 1
+    assert is_sphere.sum() == 2 and len(f["tris"]) == 10
+    assert sorted(f["prim_of_tri"][is_sphere]) == [6, 9] and sorted(f["prim_of_tri"][~is_sphere]) == [0, 1, 2, 3, 4, 5, 7, 8]
+    rec = f["tris"][is_sphere][np.argsort(f["prim_of_tri"][is_sphere])]
+    assert np.array_equal(rec[:, 0:3], np.array([[200, 150, 300], [400, 100, 200]], np.float32))
+    assert np.array_equal(rec[:, 4:6], np.array([[80, 6400], [50, 2500]], np.float32))
+    assert list(rec[:, 7].view(np.int32)) == [1, 3] and list((rec[:, 15].view(np.uint32) & 0x7FFFFFFF)) == [1, 3]
+    assert f["materials"].shape[0] == 4 and f["materials"][3][0] == 2
+    a, b = sc.bvh_dump(-1), osc.bvh_dump(-1)
+    assert np.array_equal(bits(a["bounds"]), bits(b["bounds"])) and np.array_equal(a["miss"], b["miss"])
+    leaf = f["nodes"][f["nodes"][:, 7].view(np.int32) >= 0]
+    tri_of_leaf = leaf[:, 7].view(np.int32)
+    k = np.flatnonzero(is_sphere[tri_of_leaf])[0]
+    c, r = f["tris"][tri_of_leaf[k], 0:3], f["tris"][tri_of_leaf[k], 4]
+    assert np.array_equal(leaf[k, 0:3], c - r) and np.array_equal(leaf[k, 4:7], c + r)
+    with pytest.raises(hp.HptError, match="cannot be a light"):
+        sc.AddSphere((0, 0, 0), 1.0, hp.Material(emission=(1, 1, 1)))
+    with pytest.raises(hp.HptError, match="positive radius"):
+        sc.AddSphere((0, 0, 0), 0.0, hp.Material())

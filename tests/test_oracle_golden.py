@@ -328,3 +328,48 @@ def test_large_scene_fixtures_of_the_compiled_reference(oracle, tag):
     assert np.array_equal(p, g["shadow_prim"]) and np.array_equal(bits(t), bits(g["shadow_t"]))
     img, _ = sc.render(RNG_MT, TRIG_LIBM, 6, 2)
     assert np.array_equal(bits(img), bits(g["img_r40x32_d6_spp2"]))
+
+
+def test_solve_quadratic_and_regularize_equal_the_compiled_reference(oracle):
+    """The two pieces of the sphere / regularisation paths that ARE live code in the reference:
+    solveQuadratic (common/MathUtils.hpp:86-100) and Material::regularize (Material.hpp:164-171)."""
+    import ctypes as C
+    g = np.load(os.path.join(G, "extras.npz"))
+    got = np.zeros_like(g["quad_out"])
+    for i, (a, b, c) in enumerate(g["quad_abc"]):
+        x0, x1 = C.c_float(), C.c_float()
+        ok = oracle.lib.orc_solve_quadratic(float(a), float(b), float(c), C.byref(x0), C.byref(x1))
+        got[i] = (ok, x0.value if ok else 0, x1.value if ok else 0)
+    assert np.array_equal(bits(got), bits(g["quad_out"]))
+    assert 0.2 < g["quad_out"][:, 0].mean() < 0.9
+    reg = np.array([oracle.lib.orc_material_regularize(float(v)) for v in g["rough_in"]], np.float32)
+    assert np.array_equal(bits(reg), bits(g["rough_out"]))
+    assert (g["rough_out"] != g["rough_in"]).any() and (g["rough_out"] == g["rough_in"]).any()
+
+
+def test_sphere_intersection_of_the_oracle(oracle):
+    """Sphere::getIntersection (common/Sphere.hpp:49-69, commented out in the reference: parity
+    unpinned) against the analytic answer: from outside the near root, from inside the far one, no
+    back-face rule, a miss beside the sphere and behind the origin; any-hit queries; spheres mixed
+    with meshes in one top-level BVH keep Scene::Add order for primitive ids."""
+    from cudapathtracer_amd import scenes
+    sc = oracle.scene(32, 32, scenes.CORNELL_CAM, 40.0)
+    shell = scenes.cornell_shell_triangles()
+    sc.add_triangles(shell[0][1], Material.make(**shell[0][2]))          # prims 0..5
+    sc.add_sphere((200, 150, 300), 80.0, Material.make(1, albedo=(.7, .5, .2), metallic=1.0, roughness=0.01))   # prim 6
+    sc.add_triangles(shell[3][1], Material.make(**shell[3][2]))          # light: prims 7, 8
+    sc.add_sphere((400, 100, 200), 50.0, Material.make(2, roughness=0.1, ior=1.5))                               # prim 9
+    sc.build()
+    assert sc.info()["num_tris"] == 8
+    o = np.array([[200, 150, 0], [200, 150, 300], [200, 150, 0], [200, 150, 500], [400, 100, 0], [200, 231, 0]], np.float32)
+    d = np.array([[0, 0, 1], [0, 0, 1], [0, 1, 0], [0, 0, 1], [0, 0, 1], [0, 0, 1]], np.float32)
+    p, t = sc.intersect(o, d)
+    assert p[0] == 6 and abs(t[0] - 220) < 1e-3          # outside: near root
+    assert p[1] == 6 and abs(t[1] - 80) < 1e-3           # centre: far root
+    assert p[2] != 6 and p[3] != 6 and p[5] != 6         # beside it / behind the origin / just above the pole
+    assert p[4] == 9 and abs(t[4] - 150) < 1e-3
+    sh, tm = np.ones(6, np.uint8), np.array([1000, 1000, 1000, 1000, 100, 1000], np.float64)
+    p, t = sc.intersect(o, d, sh, tm)
+    assert p[0] == 6 and p[1] == 6 and p[4] == -1        # the glass sphere lies beyond tmax = 100
+    img, st = sc.render(RNG_PHILOX, TRIG_PORTABLE, 6, 4)
+    assert np.isfinite(img).all() and img.max() > 0
