@@ -479,6 +479,94 @@ HD bool tri_hit(const float4* __restrict__ T, int tri, f3 o, f3 d, double& t_out
     return true;
 }
 
+// ---- the same test with the double division taken out of the common case ------------------
+// Triangle::getIntersection decides with u = un * (1/det), v = vn * (1/det), t = tn * (1/det)
+// (un, vn, tn, det: the four float dot products; the products and 1/det in double).  For
+// 1e-5 <= det < 1e30 the double 1/det is positive and finite and no product can underflow, so
+//   un < 0 => u < 0,  vn < 0 => v < 0,  tn < 0 => t < 0           (signs are exact; -0 is not < 0)
+//   un + vn > det * (1 + 2e-6)  (float sum of two non-negative terms, relative error 6e-8)
+//                               => u + v > 1 in double             (relative error 1e-15)
+//   un, vn, tn >= 0 and un + vn <= det * (1 - 2e-6) => u <= u + v <= 1: accepted
+// decide all but a sliver of the cases without the division; everything else (the sliver, a
+// negative, huge or NaN det, NaN numerators: every comparison above is false for them) takes the
+// reference's sequence on the same four floats.
+struct TriNum {
+    float det, un, vn, tn;
+};
+constexpr float kTriUp = 1.000002f, kTriDown = 0.999998f, kTriAbs = 1.0e-30f;
+
+HD TriNum tri_numerators(const float4* __restrict__ T, int tri, f3 o, f3 d) {
+    const f3 v0 = xyz(T[4 * tri]), e1 = xyz(T[4 * tri + 1]), e2 = xyz(T[4 * tri + 2]);
+    const f3 pvec = cross(d, e2);
+    TriNum n;
+    n.det = dot(e1, pvec);
+    const f3 tvec = o - v0;
+    n.un = dot(tvec, pvec);
+    const f3 qvec = cross(tvec, e1);
+    n.vn = dot(d, qvec);
+    n.tn = dot(e2, qvec);
+    return n;
+}
+// tri_hit<true>'s verdict from the four floats.  `ta`: tn / det to within 3e-7 relative + 1.2e-38
+// absolute when the fast rules decided, NaN otherwise (a NaN makes every later comparison fall
+// through to the exact one).  Written without early exits: in a wave some lane nearly always
+// needs the whole test (staged exits measured 4 % slower).
+HD bool tri_classify(const TriNum& n, float& ta) {
+    const bool regular = n.det >= kEpsilon5 && n.det < 1.0e30f;
+    const float s = n.un + n.vn;
+    const float lo = fminf(fminf(n.un, n.vn), n.tn);
+    const bool sure_miss = regular && (lo < 0.f || s > n.det * kTriUp);
+    bool hit = regular && lo >= 0.f && s <= n.det * kTriDown;
+    ta = n.tn * __builtin_amdgcn_rcpf(n.det);  // 1 ulp + 0.5 ulp; det < 1e30 keeps the reciprocal normal
+    if (!(sure_miss || hit)) {
+        ta = __builtin_nanf("");
+        if (!(fabsf(n.det) < kEpsilon5)) {
+            const double det_inv = reciprocal_of_float(n.det);
+            const double u = (double)n.un * det_inv, v = (double)n.vn * det_inv, t = (double)n.tn * det_inv;
+            hit = !(u < 0 || u > 1) && !(v < 0 || u + v > 1) && !(t < 0);
+        }
+    }
+    return hit;
+}
+// the reference's t for an accepted triangle, from its two floats
+HD double tri_exact_t(float tn, float det) { return (double)tn * reciprocal_of_float(det); }
+
+// Closest hit so far as (triangle, its tn and det): its exact t is only computed when a query
+// ends or when two candidates are too close to order by their float quotients.  The margins
+// (2e-6 relative, 1e-30 absolute) exceed the error of both quotients together, so "clearly
+// smaller" here implies strictly smaller in the reference's doubles.
+struct Nearest {
+    int tri;
+    float ta, tn, det;
+};
+HD Nearest nearest_none() { return Nearest{-1, kInfinity, 0.f, 1.f}; }  // "no hit" is t = kInfinity, as in trace<>
+// kTie: among equal t the lower index wins (walks that do not test in the reference's order)
+template <bool kTie>
+HD void nearest_update(Nearest& b, int tri, const TriNum& n, float ta) {
+    bool take = ta * kTriUp + kTriAbs < b.ta;
+    if (!take && !(ta > b.ta * kTriUp + kTriAbs)) {
+        const double tc = tri_exact_t(n.tn, n.det);
+        const double tb = b.tri < 0 ? (double)kInfinity : tri_exact_t(b.tn, b.det);
+        take = tc < tb || (kTie && tc == tb && tri < b.tri);
+        if (take && !(ta == ta)) ta = (float)tc;
+    }
+    if (take) {
+        b.tri = tri;
+        b.ta = ta;
+        b.tn = n.tn;
+        b.det = n.det;
+    }
+}
+HD double nearest_t(const Nearest& b) { return b.tri < 0 ? (double)kInfinity : tri_exact_t(b.tn, b.det); }
+// any-hit rule t < limit (BVH.hpp:121-127) for an accepted triangle; limit_f = (float)limit.
+// 1 = occludes, 0 = does not, -1 = too close to tell from the float quotient (the sampled light
+// triangle itself always is: its t lies within 1e-4 of the light's distance)
+HD int tri_occludes_fast(float ta, float limit_f) {
+    if (ta * kTriUp + kTriAbs < limit_f) return 1;
+    if (ta > limit_f * kTriUp + kTriAbs) return 0;
+    return -1;
+}
+
 // BVHAccel::getIntersection (common/BVH.hpp:91-145) over the flattened tree:
 //   node visited after a box hit  = i + 1        (nextIfHit  = pre-order successor, BVH.cpp:53-62)
 //   node visited after a box miss = miss link    (nextIfMiss, BVH.cpp:22-37)
@@ -613,27 +701,53 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
                 m = rest;
             }
         }
+        Nearest nb = nearest_none();
+        const float limit_f = (float)limit;
+        // any-hit: the first accepted triangle whose t is too close to the limit for the float
+        // quotient waits here; its division runs once, after the loop (a second one is settled at once)
+        int wait_tri = -1;
+        float wait_tn = 0.f, wait_det = 1.f;
         while (pending) {
             PROF_ITER(kShadow ? kProfTriS : kProfTriC);
             COUNT_TRI(1);
             const int tri = kMask32 ? __ffs((int)pending) - 1 : __ffsll((long long)pending) - 1;
             pending &= pending - 1;
-            double t;
-            if (tri_hit<true>(T, tri, o, d, t)) {
+            const TriNum n = tri_numerators(T, tri, o, d);
+            float ta;
+            if (tri_classify(n, ta)) {
                 if constexpr (kShadow) {
-                    if (t < limit) {
-                        best = tri;
-                        best_t = t;
+                    int occ = tri_occludes_fast(ta, limit_f);
+                    if (occ < 0) {
+                        if (wait_tri < 0) {
+                            wait_tri = tri;
+                            wait_tn = n.tn;
+                            wait_det = n.det;
+                            occ = 0;
+                        } else {
+                            occ = tri_exact_t(n.tn, n.det) < limit ? 1 : 0;
+                        }
+                    }
+                    if (occ > 0) {
+                        nb.tri = tri;
+                        nb.tn = n.tn;
+                        nb.det = n.det;
                         pending = 0;
                     }
                 } else {
-                    if (t < best_t) {
-                        best = tri;
-                        best_t = t;
-                    }
+                    nearest_update<false>(nb, tri, n, ta);  // ascending index = the reference's order: strict <
                 }
             }
         }
+        if constexpr (kShadow) {
+            // the waiting triangle precedes whatever ended the loop: it is the reference's first occluder if it passes
+            if (wait_tri >= 0 && tri_exact_t(wait_tn, wait_det) < limit) {
+                nb.tri = wait_tri;
+                nb.tn = wait_tn;
+                nb.det = wait_det;
+            }
+        }
+        best = nb.tri;
+        best_t = nearest_t(nb);
         PROF_T1(kShadow ? kProfTriS : kProfTriC);  // filter + tests (includes the box time, subtracted by the reader)
     } else if constexpr (kScene == kScenePair || kScene == kScenePairLds || kScene == kScenePairCull) {
         // Depth-first over two-child records.  A record is visited iff its node's box was hit,

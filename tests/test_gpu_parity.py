@@ -80,6 +80,45 @@ def test_intersect_mixed_and_degenerate(cornell):
     _check_hits(ctx.intersect(o, d), osc.intersect(o, d), "axis-parallel")
 
 
+def test_intersect_edges_vertices_and_limits(cornell):
+    """The cases the division-free triangle classification hands to the exact sequence: rays aimed at points
+    ON triangle edges, shared diagonals and vertices (u, v, u + v within rounding of 0 or 1; two triangles with
+    near-equal t), and any-hit queries whose tmax lies within a few ulps / 1e-4 of a hit distance."""
+    sc, osc, ctx = cornell
+    fa = sc.flat_arrays()
+    T = fa["tris"]
+    v0, e1, e2 = T[:, 0:3], T[:, 4:7], T[:, 8:11]
+    rs = np.random.RandomState(11)
+    n = 1 << 15
+    tri = rs.randint(0, len(T), n)
+    s = rs.rand(n).astype(np.float32)[:, None]
+    kind = rs.randint(0, 5, n)[:, None]
+    target = np.where(kind == 0, v0[tri] + s * e1[tri],                       # edge v0-v1
+             np.where(kind == 1, v0[tri] + s * e2[tri],                       # edge v0-v2
+             np.where(kind == 2, v0[tri] + e1[tri] + s * (e2[tri] - e1[tri]),  # edge v1-v2 (the rectangles' diagonals)
+             np.where(kind == 3, v0[tri] + np.where(s < 0.5, e1[tri], e2[tri]), v0[tri])))).astype(np.float32)
+    o = (rs.rand(n, 3) * [556, 548.8, 559.2]).astype(np.float32)
+    v = (target - o).astype(np.float32)
+    ln = np.sqrt((v[:, 0] * v[:, 0] + v[:, 1] * v[:, 1]) + v[:, 2] * v[:, 2], dtype=np.float32)
+    keep = ln > 1e-3
+    o, v, ln = o[keep], v[keep], ln[keep]
+    d = (v * (np.float32(1) / ln)[:, None]).astype(np.float32)
+    want = osc.intersect(o, d)
+    _check_hits(ctx.intersect(o, d), want, "edges and vertices, closest")
+    # any-hit with tmax around the closest hit's distance: the occlusion rule t < tmax - 1e-4 at its boundary
+    hit = want[0] >= 0
+    o, d, t = o[hit], d[hit], want[1][hit]
+    deltas = np.array([0.0, 1e-4, 9.99e-5, 1.001e-4, 1e-4 + 1e-9, 1e-4 - 1e-9, 2e-4, 5e-5, -1e-4, 1e-3, -1e-3])
+    tm = (t[:, None] + deltas[None, :]).astype(np.float32).astype(np.float64)  # Ray::shadowDistance holds a float's value
+    o = np.repeat(o, len(deltas), axis=0)
+    d = np.repeat(d, len(deltas), axis=0)
+    tm = tm.reshape(-1)
+    sh = np.ones(len(o), np.uint8)
+    want = osc.intersect(o, d, sh, tm)
+    assert 0.05 < (want[0] >= 0).mean() < 0.95
+    _check_hits(ctx.intersect(o, d, sh, tm), want, "any-hit at the limit")
+
+
 def test_intersect_empty_batch(cornell):
     sc, osc, ctx = cornell
     p, t = ctx.intersect(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
