@@ -106,6 +106,14 @@ HD float sqrt_rn(float x) {
     const float r = __builtin_fmaf(-s, s, x);
     return __builtin_fmaf(r, h, s);
 }
+// 2.0f / x: twice the correctly rounded reciprocal where neither can leave the normal range
+HD float two_over(float x) {
+    const float ax = fabsf(x);
+    if (!(ax >= 1.0e-30f && ax <= 1.0e30f)) return 2.0f / x;
+    const float r = __builtin_amdgcn_rcpf(x);
+    const float e = __builtin_fmaf(-x, r, 1.0f);
+    return 2.0f * __builtin_fmaf(e, r, r);
+}
 HD float length(f3 v) { return sqrt_rn(dot(v, v)); }
 HD f3 normalize(f3 v) { return v * rcp_rn(sqrt_rn(dot(v, v))); }
 HD float gmax(float x, float y) { return x > y ? x : y; }  // glm::max (external/glm/detail/func_common.inl:23-28): NaN -> y
@@ -1361,11 +1369,15 @@ HD void mat_eval(const DevMaterial& m, f3 src, f3 out, f3 normal, f3& bsdf, floa
     const float D = m.rsq / denominator;
     const float jac = mdo == 0.0f ? 0.0f : rcp_rn(4 * fabsf(mdo));  // reflect_jacobian (:100-102)
     pdf = (D * andm) * jac;
-    const float G = 2.0f / lerp(fabsf(2 * nds * ndo), fabsf(nds + ndo), m.roughness);  // geometry (:59-61)
+    const float G = two_over(lerp(fabsf(2 * nds * ndo), fabsf(nds + ndo), m.roughness));  // geometry (:59-61)
     const f3 f0 = mk(m.f0[0], m.f0[1], m.f0[2]);
     const f3 F = f0 + (mk(1.0f) - f0) * pow5(1.0f - mdo);
     const f3 kd = (mk(1.0f) - F) * m.one_minus_metallic;
-    const f3 diffuse = kd * mk(m.albedo[0], m.albedo[1], m.albedo[2]) / kPi;  // "* 1.f" of PiInv is exact
+    // "* 1.f" of PiInv is exact.  A fully metallic surface has kd = +0: +0 / Pi is +0, and a wave whose
+    // microfacet lanes are all of that kind skips the three IEEE divisions
+    const f3 kda = kd * mk(m.albedo[0], m.albedo[1], m.albedo[2]);
+    f3 diffuse = mk(0.0f);
+    if ((__float_as_uint(kda.x) | __float_as_uint(kda.y) | __float_as_uint(kda.z)) != 0u) diffuse = kda / kPi;
     const f3 specular = D * F * G / 4.0f;
     bsdf = diffuse + specular;
 }
@@ -1375,20 +1387,33 @@ HD f3 glass_direction(f3 observation_dir, f3 micro, float ior, float r2) {
     if (r2 < f) return reflect(observation_dir, micro);
     return refract(observation_dir, micro, ior);
 }
-// Material::sample (Material.hpp:186-219); r0/r1/r2 are draws kSlotBsdf0/1/2
+// Material::sample (Material.hpp:186-219); r0/r1/r2 are draws kSlotBsdf0/1/2.
+// A wave usually holds lanes on Lambertian and on microfacet surfaces and then runs both
+// branches, so what the two have in common is computed once, outside them: both turn r1 into an
+// azimuth -- sampleHemisphereCosine's `ry * Pi * 2.0f` and the microfacet `2 * Pi * r1` are the same
+// float (a factor of 2 is exact) -- and both end in local_to_world about the normal.  Per lane the
+// operations and their order are those of the reference.
 template <bool kExt>
 HD f3 mat_sample(const DevMaterial& m, float r0, float r1, float r2, f3 ray_out_dir, f3 normal) {
-    if (m.type == 0) return sampleHemisphereCosine(normal, r0, r1);
-    const float theta = portable_acos(sqrt_rn((1.0f - r0) / (m.rsq_minus_1 * r0 + 1.0f)));
-    const float phi = 2 * kPi * r1;
-    float st, ct, sp, cp;
-    portable_sincos(theta, st, ct);
-    portable_sincos(phi, sp, cp);
-    const f3 micro = local_to_world(mk(st * cp, st * sp, ct), normal);
-    if constexpr (kExt) {
-        if (m.type == 2) return glass_direction(-ray_out_dir, micro, m.ior, r2);
+    float sp, cp;
+    portable_sincos(r1 * kPi * 2.0f, sp, cp);
+    f3 local;
+    if (m.type == 0) {  // sampleHemisphereCosine (MathUtils.hpp:187-197)
+        const float r = sqrt_rn(r0);
+        const float dx = cp * r, dy = sp * r;
+        local = mk(dx, dy, sqrt_rn(1.f - (dx * dx + dy * dy)));
+    } else {
+        const float theta = portable_acos(sqrt_rn((1.0f - r0) / (m.rsq_minus_1 * r0 + 1.0f)));
+        float st, ct;
+        portable_sincos(theta, st, ct);
+        local = mk(st * cp, st * sp, ct);
     }
-    return reflect(-ray_out_dir, micro);
+    const f3 w = local_to_world(local, normal);  // the sampled direction (Lambert) or the micro-normal
+    if (m.type == 0) return w;
+    if constexpr (kExt) {
+        if (m.type == 2) return glass_direction(-ray_out_dir, w, m.ior, r2);
+    }
+    return reflect(-ray_out_dir, w);
 }
 
 // Material and shading normal of a hit.  kExt: the table of regularised materials serves a path
