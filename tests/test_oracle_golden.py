@@ -373,3 +373,25 @@ def test_sphere_intersection_of_the_oracle(oracle):
     assert p[0] == 6 and p[1] == 6 and p[4] == -1        # the glass sphere lies beyond tmax = 100
     img, st = sc.render(RNG_PHILOX, TRIG_PORTABLE, 6, 4)
     assert np.isfinite(img).all() and img.max() > 0
+
+
+def test_cpu_path_tracer_cli_writes_the_reference_picture(oracle, tmp_path):
+    """oracle/cpu_path_tracer <spp> <maxDepth> <threads> (the reference's CPU front end, cpu_path_tracer/main.cpp:16-56,
+    over the restatement): its PPM equals the compiled reference renderer's image (fixture) through the reference's
+    tone curve, byte for byte; stdout carries the reference's lines."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(G), "..", "oracle", "cpu_path_tracer")
+    assert os.path.exists(exe), "oracle/cpu_path_tracer is missing: run `make oracle`"
+    env = dict(os.environ, HPT_MODELS_DIR=os.path.join(os.path.dirname(G), "..", "models"), HPT_WIDTH="64", HPT_HEIGHT="64")
+    r = subprocess.run([exe, "4", "5", "3"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "OpenMP: Enabled, #threads=3" in r.stdout and "Render complete: " in r.stdout and "Time taken: 0 hours" in r.stdout
+    data = open(os.path.join(tmp_path, "out", "cpu", "Cornell Box.ppm"), "rb").read()
+    header = b"P6\n64 64\n255\n"
+    assert data.startswith(header)
+    got = np.frombuffer(data[len(header):], np.uint8).reshape(-1, 3)
+    g = np.load(os.path.join(G, "cornell_images.npz"))["r64_d5_spp4"]
+    want = np.array([[oracle.lib.orc_tonemap(float(v)) for v in px] for px in g], np.uint8)
+    assert np.array_equal(got, want)
+    r = subprocess.run([exe, "0", "5", "3"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "usage" in r.stderr
