@@ -17,6 +17,13 @@
 
 #include "../../include/hpt.h"
 
+// rcp_rn, sqrt_rn, two_over and reciprocal_of_float below are correctly rounded because gfx950's
+// v_rcp / v_sqrt / v_rsq approximations make them so (checked for every float by
+// tools/micro/exact_math_check.hip, which includes this header); another GPU's approximations are unverified.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "hpt_device.h is written and verified for gfx950 only"
+#endif
+
 namespace hpt {
 
 // Diagnostic build only (-DHPT_PROFILE): per-section shader-clock and lane-occupancy
@@ -516,7 +523,8 @@ HD TriNum tri_numerators(const float4* __restrict__ T, int tri, f3 o, f3 d) {
     return n;
 }
 // tri_hit<true>'s verdict from the four floats.  `ta`: tn / det to within 3e-7 relative + 1.2e-38
-// absolute when the fast rules decided, NaN otherwise (a NaN makes every later comparison fall
+// absolute when the fast rules decided (+inf when the quotient exceeds the float range: farther than
+// any hit or limit it is compared with), NaN otherwise (a NaN makes every later comparison fall
 // through to the exact one).  Written without early exits: in a wave some lane nearly always
 // needs the whole test (staged exits measured 4 % slower).
 HD bool tri_classify(const TriNum& n, float& ta) {
