@@ -27,7 +27,7 @@ PKG   := cudapathtracer_amd
 CSRC  := $(PKG)/csrc
 HOST  := $(PKG)/host
 
-HOST_SRCS := $(HOST)/BVH.cpp $(HOST)/Scene.cpp $(HOST)/SceneFile.cpp $(HOST)/Triangle.cpp $(HOST)/Utility.cpp \
+HOST_SRCS := $(HOST)/BVH.cpp $(HOST)/Material.cpp $(HOST)/Scene.cpp $(HOST)/SceneFile.cpp $(HOST)/Triangle.cpp $(HOST)/Utility.cpp \
              $(HOST)/HipRenderer.cpp $(HOST)/host_capi.cpp
 HOST_HDRS := $(wildcard $(HOST)/*.hpp) include/hpt.h include/hpt_host.h
 

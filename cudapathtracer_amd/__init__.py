@@ -2,5 +2,5 @@
 kevinsadi/CudaPathTracer (Scene / HipRenderer), see api.py."""
 from .api import (Context, HipRenderer, HptError, Material, SavePPM, SavePFM, Scene, SingleKernel, Streamed,  # noqa: F401
                   TRAVERSAL_CULLED, TRAVERSAL_REFERENCE,
-                  accum_reduce, device_count, load_libraries)
+                  accum_reduce, device_count, load_libraries, material_eval, material_sample, rng_floats)
 from .sharding import reduce_accum, render_sharded, sample_range  # noqa: F401

@@ -149,6 +149,10 @@ def _declare(L, H):
     H.hpt_host_render_iterative.argtypes = [vp, i32, i32, i32, i32, i32, vp, C.POINTER(hpt_stats)]
     H.hpt_host_render_devices.argtypes = [vp, C.POINTER(C.c_int), i32, i32, i32, i32, i32, i32, vp, C.POINTER(hpt_stats)]
     H.hpt_host_save_ppm.argtypes = [C.c_char_p, vp, i32, i32]
+    H.hpt_host_scene_intersect.argtypes = [vp, i32, C.c_size_t] + [vp] * 11
+    H.hpt_host_material_eval.argtypes = [C.POINTER(hpt_material), C.c_size_t] + [vp] * 5
+    H.hpt_host_material_sample.argtypes = [C.POINTER(hpt_material), C.c_size_t] + [vp] * 4
+    H.hpt_host_rng_floats.argtypes = [i32, i32, i32, vp]
     H.hpt_host_save_pfm.argtypes = [C.c_char_p, vp, i32, i32]
 
 
@@ -305,6 +309,23 @@ class Scene:
         _ckh(self._H.hpt_host_bvh_dump(self._h, mesh, C.byref(n), b.ctypes.data, p.ctypes.data, a.ctypes.data,
                                        m.ctypes.data))
         return dict(bounds=b, payload=p, area=a, miss=m)
+
+    def intersect(self, o, d, shadow=None, tmax=None, device=0):
+        """Scene::intersect (common/Scene.hpp:95-97) of the C++ host class on a batch of rays, run on the GPU.
+        Returns a dict of the Intersection fields (happened, prim, distance, coords, normal, triangleArea, material_type)."""
+        o = np.ascontiguousarray(o, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
+        n = len(o)
+        sh = None if shadow is None else np.ascontiguousarray(shadow, np.uint8)
+        tm = None if tmax is None else np.ascontiguousarray(tmax, np.float64)
+        out = dict(happened=np.zeros(n, np.uint8), prim=np.zeros(n, np.int32), distance=np.zeros(n, np.float64),
+                   coords=np.zeros((n, 3), np.float32), normal=np.zeros((n, 3), np.float32),
+                   triangleArea=np.zeros(n, np.float32), material_type=np.zeros(n, np.int32))
+        _ckh(self._H.hpt_host_scene_intersect(self._h, int(device), n, o.ctypes.data, d.ctypes.data,
+                                              None if sh is None else sh.ctypes.data, None if tm is None else tm.ctypes.data,
+                                              *[out[k].ctypes.data for k in ("happened", "prim", "distance", "coords", "normal",
+                                                                             "triangleArea", "material_type")]))
+        return out
 
     def render_cpp(self, spp, max_depth, num_threads=256, mode=SingleKernel, device=0, iterative=False, devices=None):
         """Render through the C++ HipRenderer class: PrepareRender/Render/FinishRender, or
@@ -498,6 +519,31 @@ class HipRenderer:
             self.RefreshFramebuffer()
             self._ctx.close()
             self._ctx = None
+
+
+def material_eval(material, ray_source_dir, ray_out_dir, normal):
+    """Material::bsdf and Material::pdf of the C++ host class (common/Material.hpp:257-384): (bsdf[n, 3], pdf[n])."""
+    a, b, c = (np.ascontiguousarray(x, np.float32).reshape(-1, 3) for x in (ray_source_dir, ray_out_dir, normal))
+    bsdf, pdf = np.zeros_like(a), np.zeros(len(a), np.float32)
+    _ckh(load_libraries()[1].hpt_host_material_eval(C.byref(material), len(a), a.ctypes.data, b.ctypes.data, c.ctypes.data,
+                                                    bsdf.ctypes.data, pdf.ctypes.data))
+    return bsdf, pdf
+
+
+def material_sample(material, u3, ray_out_dir, normal):
+    """Material::sample of the C++ host class (common/Material.hpp:186-219) with the three uniform draws given per sample in the order the method draws them."""
+    u, b, c = (np.ascontiguousarray(x, np.float32).reshape(-1, 3) for x in (u3, ray_out_dir, normal))
+    out = np.zeros_like(b)
+    _ckh(load_libraries()[1].hpt_host_material_sample(C.byref(material), len(b), u.ctypes.data, b.ctypes.data, c.ctypes.data,
+                                                      out.ctypes.data))
+    return out
+
+
+def rng_floats(iter, index, count):
+    """The first floats of the host RNG(iter, index) (common/MathUtils.hpp:22-36)."""
+    out = np.zeros(count, np.float32)
+    _ckh(load_libraries()[1].hpt_host_rng_floats(int(iter), int(index), int(count), out.ctypes.data))
+    return out
 
 
 def SavePPM(path, framebuffer, width, height):

@@ -55,6 +55,8 @@ float Scene::cameraScale() const {
 // follows the leaf; a sphere is a leaf of the top level itself.
 void Scene::buildBVH() {
     if (objects.empty()) throw std::runtime_error("Scene::buildBVH: scene has no meshes");
+    query_ctx_.reset();  // intersect() uploads the new scene on its next call
+    tri_of_prim_.clear();
     std::vector<Object*> top_objects;
     for (const ObjectRef& o : objects) top_objects.push_back(o.sphere ? (Object*)spheres[o.index] : (Object*)meshes[o.index]);
     bvh_owner_ = std::make_shared<BVHAccel>(top_objects, 1, BVHAccel::SplitMethod::NAIVE);
@@ -184,6 +186,65 @@ const FlatScene& Scene::flat() const {
     if (!flat_) throw std::runtime_error("Scene: buildBVH() has not been called");
     return *flat_;
 }
+
+std::vector<Intersection> Scene::intersect(const std::vector<Ray>& rays) const {
+    const FlatScene& f = flat();
+    if (!query_ctx_) {
+        hpt_ctx* ctx = nullptr;
+        if (hpt_context_create(query_device, &ctx) != HPT_OK) throw std::runtime_error(std::string("Scene::intersect: ") + hpt_last_error());
+        query_ctx_ = std::shared_ptr<hpt_ctx>(ctx, [](hpt_ctx* c) { hpt_context_destroy(c); });
+        const hpt_scene_desc d = describe();
+        if (hpt_scene_upload(ctx, &d) != HPT_OK) {
+            query_ctx_.reset();
+            throw std::runtime_error(std::string("Scene::intersect: ") + hpt_last_error());
+        }
+        int32_t prims = 0;
+        for (int32_t p : f.prim_of_tri) prims = std::max(prims, p + 1);
+        tri_of_prim_.assign((size_t)prims, -1);
+        for (size_t t = 0; t < f.prim_of_tri.size(); ++t) tri_of_prim_[(size_t)f.prim_of_tri[t]] = (int32_t)t;
+    }
+    const size_t n = rays.size();
+    std::vector<Intersection> out(n);
+    if (n == 0) return out;
+    std::vector<float> o(3 * n), d(3 * n);
+    std::vector<uint8_t> shadow(n);
+    std::vector<double> tmax(n), t(n);
+    std::vector<int32_t> prim(n);
+    for (size_t i = 0; i < n; ++i) {
+        const Ray& r = rays[i];
+        o[3 * i] = r.origin.x; o[3 * i + 1] = r.origin.y; o[3 * i + 2] = r.origin.z;
+        d[3 * i] = r.direction.x; d[3 * i + 1] = r.direction.y; d[3 * i + 2] = r.direction.z;
+        shadow[i] = r.shadowTest ? 1 : 0;
+        tmax[i] = r.shadowDistance;
+    }
+    if (hpt_intersect_batch(query_ctx_.get(), n, o.data(), d.data(), shadow.data(), tmax.data(), prim.data(), t.data()) != HPT_OK)
+        throw std::runtime_error(std::string("Scene::intersect: ") + hpt_last_error());
+    for (size_t i = 0; i < n; ++i) {
+        if (prim[i] < 0) continue;
+        Intersection& in = out[i];
+        const float* rec = f.tris.data + 16 * (size_t)tri_of_prim_[(size_t)prim[i]];
+        uint32_t mat, tag;
+        std::memcpy(&mat, rec + 7, 4);
+        std::memcpy(&tag, rec + 15, 4);
+        in.happened = true;
+        in.primitive = prim[i];
+        in.distance = t[i];
+        in.coords = rays[i](t[i]);  // Triangle.hpp:191
+        const ObjectRef ref = objects[mat];  // one material per object, in Add order
+        if (tag & 0x80000000u) {  // a sphere record: center, then radius (Sphere.hpp:62, commented out in the reference)
+            in.normal = normalize(in.coords - Vec3(rec[0], rec[1], rec[2]));
+            in.m = spheres[ref.index]->material;
+        } else {
+            in.normal = Vec3(rec[12], rec[13], rec[14]);
+            in.triangleArea = rec[3];
+            in.m = meshes[ref.index]->material;
+        }
+        in.emit = in.m._emission;
+    }
+    return out;
+}
+
+Intersection Scene::intersect(const Ray& ray) const { return intersect(std::vector<Ray>{ray})[0]; }
 
 hpt_scene_desc Scene::describe() const {
     const FlatScene& f = flat();

@@ -1,9 +1,9 @@
 // Scene: the host-side scene description with the public members and methods
 // of the reference's Scene that callers use (common/Scene.hpp:20-93):
 // resolution, camera, maxDepth, Add(), buildBVH(), CreateBuiltinScene(), the
-// light totals.  intersect/TracePath/castRay are not host functions here: the
-// bounce loop runs on the device; buildBVH() additionally emits the flattened
-// records that hpt_scene_upload() consumes.
+// light totals, intersect().  TracePath/castRay are not host functions here: the
+// bounce loop runs on the device, and so do the queries of intersect(); buildBVH()
+// additionally emits the flattened records that hpt_scene_upload() consumes.
 #pragma once
 #include <memory>
 #include <string>
@@ -11,6 +11,7 @@
 
 #include "../../include/hpt.h"
 #include "BVH.hpp"
+#include "Ray.hpp"
 #include "Triangle.hpp"
 
 // 64-byte aligned storage for the flattened arrays
@@ -99,6 +100,14 @@ public:
     // (common/Renderer.cpp:11,20)
     float cameraScale() const;
 
+    // Scene::intersect (common/Scene.hpp:95-97 -> BVHAccel::Intersect) for host callers: closest hit, or the
+    // any-hit answer for a ray with shadowTest set.  The queries run on GPU `query_device` through
+    // hpt_intersect_batch (the scene is uploaded to a context of its own on first use); pass many rays at once
+    // where possible -- a single ray costs a kernel launch.  Throws std::runtime_error without a GPU.
+    Intersection intersect(const Ray& ray) const;
+    std::vector<Intersection> intersect(const std::vector<Ray>& rays) const;
+    int query_device = 0;
+
     // valid after buildBVH(); pointers inside stay valid while the scene lives
     const FlatScene& flat() const;
     hpt_scene_desc describe() const;
@@ -109,4 +118,6 @@ private:
     std::shared_ptr<BVHAccel> bvh_owner_;
     std::vector<std::shared_ptr<BVHAccel>> mesh_bvh_owner_;
     std::shared_ptr<FlatScene> flat_;
+    mutable std::shared_ptr<hpt_ctx> query_ctx_;   // intersect(): created and uploaded on first use
+    mutable std::vector<int32_t> tri_of_prim_;     // global primitive id -> triangle record
 };

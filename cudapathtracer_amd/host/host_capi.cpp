@@ -8,6 +8,7 @@
 #include <iostream>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "HipRenderer.hpp"
 #include "Scene.hpp"
@@ -270,6 +271,71 @@ int hpt_host_render_iterative(const hpt_host_scene* s, int device, int spp, int 
         if (stats) *stats = r.Stats();
         r.FinishRender(sc);  // downloads accumulated / spp
         std::memcpy(rgb, r.framebuffer.data(), r.framebuffer.size() * sizeof(Vec3));
+    })
+}
+
+int hpt_host_scene_intersect(const hpt_host_scene* s, int device, size_t n, const float* o, const float* d, const uint8_t* shadow,
+                            const double* tmax, uint8_t* happened, int32_t* prim, double* distance, float* coords, float* normal,
+                            float* triangle_area, int32_t* material_type) {
+    if (!s || (n && (!o || !d))) return fail("null argument");
+    GUARD({
+        const_cast<Scene&>(s->scene).query_device = device;
+        std::vector<Ray> rays(n);
+        for (size_t i = 0; i < n; ++i)
+            rays[i] = Ray(Vec3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), Vec3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), shadow && shadow[i],
+                          shadow && shadow[i] && tmax ? tmax[i] : kDoubleInfinity);
+        const std::vector<Intersection> hits = s->scene.intersect(rays);
+        for (size_t i = 0; i < n; ++i) {
+            const Intersection& h = hits[i];
+            if (happened) happened[i] = h.happened ? 1 : 0;
+            if (prim) prim[i] = h.primitive;
+            if (distance) distance[i] = h.distance;
+            if (coords) { coords[3 * i] = h.coords.x; coords[3 * i + 1] = h.coords.y; coords[3 * i + 2] = h.coords.z; }
+            if (normal) { normal[3 * i] = h.normal.x; normal[3 * i + 1] = h.normal.y; normal[3 * i + 2] = h.normal.z; }
+            if (triangle_area) triangle_area[i] = h.triangleArea;
+            if (material_type) material_type[i] = h.happened ? h.m.type : -1;
+        }
+    })
+}
+
+int hpt_host_material_eval(const hpt_material* material, size_t n, const float* ray_source_dir, const float* ray_out_dir,
+                           const float* normal, float* bsdf, float* pdf) {
+    if (!material || (n && (!ray_source_dir || !ray_out_dir || !normal))) return fail("null argument");
+    GUARD({
+        const Material m = to_material(material);
+        for (size_t i = 0; i < n; ++i) {
+            const Vec3 src(ray_source_dir[3 * i], ray_source_dir[3 * i + 1], ray_source_dir[3 * i + 2]);
+            const Vec3 out(ray_out_dir[3 * i], ray_out_dir[3 * i + 1], ray_out_dir[3 * i + 2]);
+            const Vec3 nrm(normal[3 * i], normal[3 * i + 1], normal[3 * i + 2]);
+            if (bsdf) {
+                const Vec3 f = m.bsdf(src, out, nrm);
+                bsdf[3 * i] = f.x; bsdf[3 * i + 1] = f.y; bsdf[3 * i + 2] = f.z;
+            }
+            if (pdf) pdf[i] = m.pdf(src, out, nrm);
+        }
+    })
+}
+
+int hpt_host_material_sample(const hpt_material* material, size_t n, const float* u3, const float* ray_out_dir, const float* normal,
+                             float* dir_out) {
+    if (!material || (n && (!u3 || !ray_out_dir || !normal || !dir_out))) return fail("null argument");
+    GUARD({
+        const Material m = to_material(material);
+        for (size_t i = 0; i < n; ++i) {
+            // u3 is in the order Material::sample(RNG&, ...) draws: a Lambertian surface's first draw is its SECOND argument
+            const bool swap = m.type == Material::Lambertian;
+            const Vec3 w = m.sample(u3[3 * i + (swap ? 1 : 0)], u3[3 * i + (swap ? 0 : 1)], u3[3 * i + 2], Vec3(ray_out_dir[3 * i], ray_out_dir[3 * i + 1], ray_out_dir[3 * i + 2]),
+                                    Vec3(normal[3 * i], normal[3 * i + 1], normal[3 * i + 2]));
+            dir_out[3 * i] = w.x; dir_out[3 * i + 1] = w.y; dir_out[3 * i + 2] = w.z;
+        }
+    })
+}
+
+int hpt_host_rng_floats(int iter, int index, int count, float* out) {
+    if (count && !out) return fail("null argument");
+    GUARD({
+        RNG rng(iter, index, 0);
+        for (int i = 0; i < count; ++i) out[i] = rng.sample1D();
     })
 }
 

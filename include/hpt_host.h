@@ -76,6 +76,24 @@ int hpt_host_render_iterative(const hpt_host_scene* s, int device, int spp, int 
  * onto devices[0].  iterative != 0: through PathTrace, sample iter on entry iter mod num_devices. */
 int hpt_host_render_devices(const hpt_host_scene* s, const int* devices, int num_devices, int spp, int max_depth,
                             int num_threads, int mode, int iterative, float* rgb, hpt_stats* stats);
+/* Scene::intersect (common/Scene.hpp:95-97) on a batch of rays, run on GPU `device` (hpt_intersect_batch on a context the
+ * scene keeps).  shadow[i] != 0 = any-hit query against tmax[i] (Ray::shadowTest / shadowDistance).  Outputs (each may be
+ * NULL) are the fields of Intersection (common/Intersection.hpp:14-35): happened, distance, coords = ray(distance), normal,
+ * triangleArea, m.type; prim = global primitive id, -1 on a miss. */
+int hpt_host_scene_intersect(const hpt_host_scene* s, int device, size_t n, const float* o, const float* d, const uint8_t* shadow,
+                             const double* tmax, uint8_t* happened, int32_t* prim, double* distance, float* coords, float* normal,
+                             float* triangle_area, int32_t* material_type);
+
+/* Material::bsdf / Material::pdf (common/Material.hpp:257-384) and Material::sample (:186-219, with the three uniform draws
+ * given per sample in u3, in the order Material::sample(RNG&) draws them) of the host Material class, n directions each; libm transcendentals like the
+ * reference's CPU build.  The renderer does not use them (materials are evaluated on the device). */
+int hpt_host_material_eval(const hpt_material* material, size_t n, const float* ray_source_dir, const float* ray_out_dir,
+                           const float* normal, float* bsdf, float* pdf);
+int hpt_host_material_sample(const hpt_material* material, size_t n, const float* u3, const float* ray_out_dir, const float* normal,
+                             float* dir_out);
+/* the first `count` floats of RNG(iter, index, 0) (common/MathUtils.hpp:22-36), the reference's host random stream */
+int hpt_host_rng_floats(int iter, int index, int count, float* out);
+
 /* Utility::SavePPM (common/Utility.cpp:4-22) */
 int hpt_host_save_ppm(const char* path, const float* rgb, int width, int height);
 /* Utility::SavePFM: linear float RGB as a portable float map (no counterpart in the reference) */

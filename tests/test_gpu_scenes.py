@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from orclib import RNG_PHILOX, TRIG_PORTABLE, Material, primary_rays, random_rays
+from orclib import RNG_PHILOX, TRIG_PORTABLE, Material, primary_rays, random_rays, shadow_rays
 
 pytestmark = pytest.mark.gpu
 
@@ -505,3 +505,35 @@ def test_russian_roulette_and_path_regularisation(hp, oracle, gpu_ctx, scene, rr
     assert np.array_equal(gpu_ctx.resolve(spp).view(np.int32), oracle.resolve(plain, spp).view(np.int32))
     with pytest.raises(hp.HptError):
         hp.api._ck(gpu_ctx._L.hpt_set_integrator(gpu_ctx._h, 8))   # an unknown flag
+
+
+def test_host_scene_intersect_equals_oracle(hp, oracle):
+    """Scene::intersect of the C++ host class (common/Scene.hpp:95-97), which runs its queries on the GPU:
+    happened / primitive / distance bit-exact against the oracle, coords = ray(distance), the hit triangle's normal,
+    area and material; closest-hit and any-hit rays in one batch; a single-ray call; an empty batch."""
+    sc = hp.Scene.CreateBuiltinScene(hp.Scene.CornellBox, 5)
+    osc = oracle.cornell()
+    o1, d1 = random_rays(20000, seed=21)
+    o2, d2, _, tm2 = shadow_rays(20000, seed=22)
+    o, d = np.concatenate([o1, o2]), np.concatenate([d1, d2])
+    sh = np.concatenate([np.zeros(20000, np.uint8), np.ones(20000, np.uint8)])
+    tm = np.concatenate([np.full(20000, 1e30), tm2])
+    want_p, want_t = osc.intersect(o, d, sh, tm)
+    got = sc.intersect(o, d, sh, tm)
+    assert np.array_equal(got["prim"], want_p) and np.array_equal(got["happened"] != 0, want_p >= 0)
+    assert np.array_equal(got["distance"].view(np.int64), want_t.view(np.int64))
+    hit = want_p >= 0
+    coords = (o + d * want_t.astype(np.float32)[:, None]).astype(np.float32)
+    assert np.array_equal(got["coords"][hit].view(np.uint32), coords[hit].view(np.uint32))
+    fa = sc.flat_arrays()
+    slot = np.full(fa["prim_of_tri"].max() + 1, -1)
+    slot[fa["prim_of_tri"]] = np.arange(len(fa["prim_of_tri"]))
+    T = fa["tris"][slot[want_p[hit]]]
+    assert np.array_equal(got["normal"][hit].view(np.uint32), T[:, 12:15].view(np.uint32))
+    assert np.array_equal(got["triangleArea"][hit].view(np.uint32), T[:, 3].view(np.uint32))
+    mat = T[:, 7].view(np.uint32)
+    assert np.array_equal(got["material_type"][hit], fa["materials"][mat, 0].astype(np.int32))
+    assert (got["material_type"][~hit] == -1).all()
+    one = sc.intersect(o[:1], d[:1])
+    assert one["prim"][0] == want_p[0] and one["distance"][0] == want_t[0]
+    assert len(sc.intersect(np.zeros((0, 3)), np.zeros((0, 3)))["prim"]) == 0

@@ -512,3 +512,36 @@ def test_sphere_in_the_flattened_scene(hp, oracle):
         sc.AddSphere((0, 0, 0), 1.0, hp.Material(emission=(1, 1, 1)))
     with pytest.raises(hp.HptError, match="positive radius"):
         sc.AddSphere((0, 0, 0), 0.0, hp.Material())
+
+
+HOST_MATS = {
+    "lambert": ("cornell_shading.npz", dict(type=0, albedo=(0.725, 0.71, 0.68))),
+    "metal": ("cornell_shading.npz", dict(type=1, albedo=(0.7, 0.5, 0.2), metallic=1.0, roughness=0.005)),
+    "metal_rough": ("cornell_shading.npz", dict(type=1, albedo=(0.9, 0.6, 0.3), metallic=0.3, roughness=0.4)),
+    "glass": ("glass.npz", dict(type=2, roughness=0.2, ior=1.5)),
+    "glass_water": ("glass.npz", dict(type=2, roughness=0.05, ior=1.33)),
+    "glass_rough": ("glass.npz", dict(type=2, roughness=0.7, ior=2.4)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(HOST_MATS))
+def test_host_material_equals_the_compiled_reference(hp, name):
+    """Material::bsdf / pdf / sample of the C++ host class against the vectors the compiled reference's Material
+    produced (common/Material.hpp:186-384; fixtures of tests/golden/make_golden.py): bit for bit."""
+    fixture, kw = HOST_MATS[name]
+    g = np.load(os.path.join(G, fixture))
+    m = hp.Material(**kw)
+    b = lambda a: np.ascontiguousarray(a).view(np.uint32)
+    bsdf, pdf = hp.material_eval(m, g["wi"], g["wo"], g["nrm"])
+    assert np.array_equal(b(bsdf), b(g[name + "_bsdf"])) and np.array_equal(b(pdf), b(g[name + "_pdf"]))
+    wi = hp.material_sample(m, g[name + "_sample_u"], g["wo"], g["nrm"])
+    assert np.array_equal(b(wi), b(g[name + "_sample_wi"]))
+    bsdf, pdf = hp.material_eval(m, wi, g["wo"], g["nrm"])
+    assert np.array_equal(b(bsdf), b(g[name + "_bsdf_at_sample"])) and np.array_equal(b(pdf), b(g[name + "_pdf_at_sample"]))
+
+
+def test_host_rng_equals_the_reference_stream(hp):
+    """RNG(iter, index) of the host side = the reference's mt19937 stream (common/MathUtils.hpp:22-36)."""
+    g = np.load(os.path.join(G, "cornell_shading.npz"))
+    assert np.array_equal(hp.rng_floats(3, 12345, 64).view(np.uint32), g["rng_k3_m12345"].view(np.uint32))
+    assert np.array_equal(hp.rng_floats(0, 0, 64).view(np.uint32), g["rng_k0_m0"].view(np.uint32))
