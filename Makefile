@@ -35,12 +35,12 @@ HOST_HDRS := $(wildcard $(HOST)/*.hpp) include/hpt.h include/hpt_host.h
 all: hpt host oracle
 
 hpt: $(PKG)/libhpt.so
-$(PKG)/libhpt.so: $(CSRC)/hpt_core.hip $(CSRC)/hpt_device.h include/hpt.h Makefile
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/hpt_core.hip
+$(PKG)/libhpt.so: $(CSRC)/hpt_core.hip $(CSRC)/hpt_bvh_build.hip $(CSRC)/hpt_device.h include/hpt.h Makefile
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/hpt_core.hip $(CSRC)/hpt_bvh_build.hip
 
 count: $(PKG)/libhpt_count.so
-$(PKG)/libhpt_count.so: $(CSRC)/hpt_core.hip $(CSRC)/hpt_device.h include/hpt.h Makefile
-	$(HIPCC) $(HIPFLAGS) -DHPT_COUNT_TESTS -shared -o $@ $(CSRC)/hpt_core.hip
+$(PKG)/libhpt_count.so: $(CSRC)/hpt_core.hip $(CSRC)/hpt_bvh_build.hip $(CSRC)/hpt_device.h include/hpt.h Makefile
+	$(HIPCC) $(HIPFLAGS) -DHPT_COUNT_TESTS -shared -o $@ $(CSRC)/hpt_core.hip $(CSRC)/hpt_bvh_build.hip
 
 host: $(PKG)/libhpt_host.so build/gpu_path_tracer
 $(PKG)/libhpt_host.so: $(HOST_SRCS) $(HOST_HDRS) $(PKG)/libhpt.so

@@ -124,6 +124,9 @@ def main():
     ap.add_argument("--traversal", default="reference", choices=["reference", "culled"],
                     help="reference = the reference's box/triangle tests exactly (the parity path); culled = near-first "
                          "order with distance culling for scenes of more than 64 triangles (opt-in, not bit-guaranteed)")
+    ap.add_argument("--bvh-build", default="host", choices=["host", "gpu"],
+                    help="host: the reference's tree (default); gpu: traversal records built on the device at upload "
+                         "(side measurement; scenes other than cornell)")
     ap.add_argument("--scene", default="cornell", help="cornell (the headline workload) | bunny | heightfield:<n> "
                     "(side measurements of the other configurations; they never change the default line)")
     args = ap.parse_args()
@@ -187,6 +190,8 @@ def main():
     else:
         from cudapathtracer_amd import scenes
         scene = scenes._assemble(scene_parts(args.scene), W, H, depth)
+        if args.bvh_build == "gpu":
+            scene.buildBVH(gpu=True)
     ctx = hp.Context(dev_index)
     if args.traversal == "culled":
         ctx.set_traversal(1)
@@ -324,6 +329,8 @@ def main():
                                        spp_step, total_spp),
                        "rays_per_path": total_rays / total_paths,
                        "traversal": args.traversal,
+                       "bvh_build": args.bvh_build if args.scene != "cornell" else "host",
+                       "gpu_bvh_build_ms": ctx.build_info()["gpu_build_ms"] or None,
                        "parallelism": ("spp-sharded x%d, one %s reduce" % (world, "RCCL" if backend == "nccl" else backend)) if use_dist else "1 GPU",
                        "collective_backend": (dist.get_backend() if use_dist else None)},
             "roofline": roof,

@@ -153,6 +153,11 @@ def _declare(L, H):
     H.hpt_host_material_eval.argtypes = [C.POINTER(hpt_material), C.c_size_t] + [vp] * 5
     H.hpt_host_material_sample.argtypes = [C.POINTER(hpt_material), C.c_size_t] + [vp] * 4
     H.hpt_host_rng_floats.argtypes = [i32, i32, i32, vp]
+    H.hpt_host_set_default_bvh_build.argtypes = [i32]
+    H.hpt_host_scene_set_bvh_build.argtypes = [vp, i32]
+    H.hpt_host_scene_bvh_build.argtypes = [vp, C.POINTER(C.c_int)]
+    L.hpt_set_bvh_build.argtypes = [vp, C.c_int]
+    L.hpt_scene_build_info.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     H.hpt_host_save_pfm.argtypes = [C.c_char_p, vp, i32, i32]
 
 
@@ -186,6 +191,7 @@ def _stream(stream):
 
 
 TRAVERSAL_REFERENCE, TRAVERSAL_CULLED = 0, 1
+BVH_BUILD_HOST, BVH_BUILD_GPU = 0, 1
 INTEGRATOR_RUSSIAN_ROULETTE, INTEGRATOR_REGULARIZE = 1, 2
 
 
@@ -224,11 +230,16 @@ class Scene:
         return s
 
     @staticmethod
-    def CreateNamedScene(name, maxDepth=10, width=0, height=0, models_dir=DEFAULT_MODELS_DIR):
-        """Scene::CreateNamedScene: "cornell" | "bunny" | "glass" | "heightfield:<n>" | "file:<scene file>"."""
+    def CreateNamedScene(name, maxDepth=10, width=0, height=0, models_dir=DEFAULT_MODELS_DIR, bvh_build=BVH_BUILD_HOST):
+        """Scene::CreateNamedScene: "cornell" | "bunny" | "glass" | "heightfield:<n>" | "file:<scene file>".
+        bvh_build=BVH_BUILD_GPU: the scene is flattened for the device-side build (Scene::default_bvh_build)."""
         H = load_libraries()[1]
         h = C.c_void_p()
-        _ckh(H.hpt_host_scene_named(name.encode(), models_dir.encode(), int(width), int(height), int(maxDepth), C.byref(h)))
+        _ckh(H.hpt_host_set_default_bvh_build(int(bvh_build)))
+        try:
+            _ckh(H.hpt_host_scene_named(name.encode(), models_dir.encode(), int(width), int(height), int(maxDepth), C.byref(h)))
+        finally:
+            H.hpt_host_set_default_bvh_build(BVH_BUILD_HOST)
         w, hh = C.c_int(), C.c_int()
         buf = C.create_string_buffer(256)
         _ckh(H.hpt_host_scene_info(h, C.byref(w), C.byref(hh), buf, 256))
@@ -259,10 +270,21 @@ class Scene:
         _ckh(self._H.hpt_host_scene_add_sphere(self._h, c.ctypes.data, float(radius), C.byref(material)))
         self._built = False
 
-    def buildBVH(self):
+    def buildBVH(self, gpu=None):
+        """Scene::buildBVH.  gpu=True: only the light meshes' trees are built on the host and the traversal records
+        are built on the device at upload (BVH_BUILD_GPU); gpu=False: the reference's two-level BVH on the host;
+        None keeps the scene's setting."""
+        if gpu is not None:
+            _ckh(self._H.hpt_host_scene_set_bvh_build(self._h, BVH_BUILD_GPU if gpu else BVH_BUILD_HOST))
         _ckh(self._H.hpt_host_scene_build(self._h))
         self._built = True
         return self
+
+    @property
+    def gpu_build(self):
+        b = C.c_int()
+        _ckh(self._H.hpt_host_scene_bvh_build(self._h, C.byref(b)))
+        return b.value == BVH_BUILD_GPU
 
     def set_resolution(self, width, height):
         _ckh(self._H.hpt_host_scene_set_resolution(self._h, int(width), int(height)))
@@ -365,11 +387,21 @@ class Context:
         self.device = int(device)
         self.width = self.height = 0
 
-    def upload(self, scene):
+    def upload(self, scene, bvh_build=None):
+        """hpt_scene_upload; a Scene built with buildBVH(gpu=True) selects BVH_BUILD_GPU by itself."""
         d = scene.describe() if isinstance(scene, Scene) else scene
+        if bvh_build is None:
+            bvh_build = BVH_BUILD_GPU if (isinstance(scene, Scene) and scene.gpu_build) else BVH_BUILD_HOST
+        _ck(self._L.hpt_set_bvh_build(self._h, int(bvh_build)))
         _ck(self._L.hpt_scene_upload(self._h, C.byref(d)))
         self.width, self.height = d.width, d.height
         return self
+
+    def build_info(self):
+        """hpt_scene_build_info: device time of a GPU build (ms), number of two-child records, stack entries."""
+        ms, n, d = C.c_double(), C.c_uint32(), C.c_uint32()
+        _ck(self._L.hpt_scene_build_info(self._h, C.byref(ms), C.byref(n), C.byref(d)))
+        return dict(gpu_build_ms=ms.value, records=n.value, stack_depth=d.value)
 
     def set_seed(self, seed):
         _ck(self._L.hpt_set_seed(self._h, int(seed)))

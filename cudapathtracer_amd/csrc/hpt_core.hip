@@ -932,6 +932,12 @@ constexpr bool has_scheduler(int variant) {
         HPT_DISPATCH_SCENE(variant, __VA_ARGS__)                                         \
     }
 
+// csrc/hpt_bvh_build.hip
+namespace hpt_build {
+std::string build_pairs(float4* tris, float4* v12, uint32_t n, const uint32_t* obj_first, uint32_t num_objects, float4* nodes, uint32_t num_nodes,
+                        float4* rec_out, uint32_t* stack_depth, uint32_t* stack_depth_any, float root_lo[3], float root_hi[3], double* build_ms);
+}
+
 // ------------------------------------------------------------------ context --
 
 struct hpt_ctx {
@@ -939,6 +945,8 @@ struct hpt_ctx {
     int num_cus = 256;
     bool has_scene = false;
     int traversal = HPT_TRAVERSAL_REFERENCE;
+    int bvh_build = HPT_BVH_BUILD_HOST;   // who derives the traversal records at hpt_scene_upload
+    double bvh_build_ms = 0.0;            // device time of the last GPU build
     // the scene has a Glass material or a sphere, or the integrator runs Russian roulette / path
     // regularisation: selects the kernels built with kExt, which carry those branches
     bool extended = false;
@@ -1770,7 +1778,27 @@ int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* sc) {
     // Two-child records of the same tree (see DevScene::pairs).  Interior node i has the children
     // i + 1 and miss(i + 1); records are numbered in pre-order of the interior nodes.
     uint32_t num_pairs = 0, stack_depth = 1, stack_depth_any = 1;
-    {
+    float root_lo[3] = {sc->nodes[0], sc->nodes[1], sc->nodes[2]}, root_hi[3] = {sc->nodes[4], sc->nodes[5], sc->nodes[6]};
+    const bool gpu_build = ctx->bvh_build == HPT_BVH_BUILD_GPU;
+    if (gpu_build) {
+        // the records come from the triangle array alone (csrc/hpt_bvh_build.hip); `nodes` only serves the light sampling
+        if (nt < 2) return fail(HPT_ERR_INVALID_ARGUMENT, "HPT_BVH_BUILD_GPU needs at least two primitives");
+        HIP_TRY(hipMemcpy(ctx->d_tris, tris.data(), nt * 64, hipMemcpyHostToDevice));
+        num_pairs = (uint32_t)nt - 1u;
+        ALLOC_TRY(ctx->d_pairs, (size_t)num_pairs * 64, "pairs");
+        // an object = a run of primitives with the same object word (word 15 without the sphere bit)
+        std::vector<uint32_t> obj_first;
+        uint32_t prev = 0xFFFFFFFFu;
+        for (size_t t = 0; t < nt; ++t) {
+            uint32_t w15;
+            std::memcpy(&w15, &tris[16 * t + 15], 4);
+            if ((w15 & ~kSphereBit) != prev || (w15 & kSphereBit)) obj_first.push_back((uint32_t)t);  // a sphere is an object of its own
+            prev = (w15 & kSphereBit) ? 0xFFFFFFFFu : (w15 & ~kSphereBit);
+        }
+        const std::string err = hpt_build::build_pairs(ctx->d_tris, ctx->d_tri_v12, (uint32_t)nt, obj_first.data(), (uint32_t)obj_first.size(), ctx->d_nodes,
+                                                       (uint32_t)nn, ctx->d_pairs, &stack_depth, &stack_depth_any, root_lo, root_hi, &ctx->bvh_build_ms);
+        if (!err.empty()) return fail(HPT_ERR_HIP, "GPU BVH build: %s", err.c_str());
+    } else {
         auto node_int = [&](size_t i, int word) {
             int32_t v;
             std::memcpy(&v, &sc->nodes[8 * i + word], 4);
@@ -1847,27 +1875,29 @@ int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* sc) {
     S.num_pairs = num_pairs;
     S.stack_depth = stack_depth;
     for (int c = 0; c < 3; ++c) {
-        S.root_lo[c] = sc->nodes[c];
-        S.root_hi[c] = sc->nodes[4 + c];
+        S.root_lo[c] = root_lo[c];
+        S.root_hi[c] = root_hi[c];
     }
     const uint64_t f4 = 2ull * nn + 4ull * nt;             // threaded nodes + triangles
     const uint64_t f4_tiny = 18ull * nn + 4ull * nt + 8ull;  // nine copies of the nodes + triangles + table
     const uint64_t f4_pair = 4ull * num_pairs + 4ull * nt;  // two-child records + triangles
-    const bool fits = f4 * 16ull <= kLdsLimit, fits_pair = f4_pair * 16ull <= kLdsLimit;
-    const bool fits_tiny = f4_tiny * 16ull <= kLdsLimitTiny;
+    // records built on the GPU: `nodes` is not the scene's tree, so only the two-child-record walks apply
+    const bool fits = !gpu_build && f4 * 16ull <= kLdsLimit, fits_pair = f4_pair * 16ull <= kLdsLimit;
+    const bool fits_tiny = !gpu_build && f4_tiny * 16ull <= kLdsLimitTiny;
     const bool pair_ok = num_pairs > 0 && stack_depth <= kMaxStackDepth;
     const bool tiny_ok = fits_tiny && !ctx->has_sphere;  // the marking variants test triangles only
     if (tiny_ok && nt <= 32) S.variant = kSceneTiny32;
     else if (tiny_ok && nt <= 64) S.variant = kSceneTiny64;
     else if (pair_ok) S.variant = fits_pair ? kScenePairLds : kScenePair;
     else S.variant = fits ? kSceneLds : kSceneGlobal;
+    if (gpu_build && !pair_ok) return fail(HPT_ERR_INVALID_ARGUMENT, "GPU BVH build: the tree needs %u stack entries (limit %u)", stack_depth, kMaxStackDepth);
     // the culled walk packs a record index into 22 bits of a stack entry
     const bool cull_ok = num_pairs > 0 && num_pairs < (1u << 22) && stack_depth_any <= kMaxStackDepth;
     if (ctx->traversal == HPT_TRAVERSAL_CULLED && cull_ok && (S.variant == kScenePair || S.variant == kScenePairLds)) S.variant = kScenePairCull;
     if (const char* e = getenv("HPT_TRACE_VARIANT")) {  // experiments: force another variant
         const int v = atoi(e);
         if (v == kScenePairCull && cull_ok) S.variant = kScenePairCull;
-        if (v == kSceneGlobal) S.variant = kSceneGlobal;
+        if (v == kSceneGlobal && !gpu_build) S.variant = kSceneGlobal;
         else if (v == kSceneLds && fits) S.variant = kSceneLds;
         else if (v == kSceneTiny64 && tiny_ok && nt <= 64) S.variant = kSceneTiny64;
         else if (v == kSceneTiny32 && tiny_ok && nt <= 32) S.variant = kSceneTiny32;
@@ -1888,7 +1918,7 @@ int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* sc) {
             std::memcpy(&tris[16 * t + 15], &group, 4);
         }
     }
-    HIP_TRY(hipMemcpy(ctx->d_tris, tris.data(), nt * 64, hipMemcpyHostToDevice));
+    if (!gpu_build) HIP_TRY(hipMemcpy(ctx->d_tris, tris.data(), nt * 64, hipMemcpyHostToDevice));  // (the GPU build has gathered its copy into leaf order)
     if (S.variant == kScenePairCull) {
         S.stack_depth = stack_depth_any;
         double diag2 = 0;
@@ -1925,6 +1955,22 @@ int hpt_set_traversal(hpt_ctx* ctx, int traversal) {
     if (traversal != HPT_TRAVERSAL_REFERENCE && traversal != HPT_TRAVERSAL_CULLED)
         return fail(HPT_ERR_INVALID_ARGUMENT, "traversal %d is neither HPT_TRAVERSAL_REFERENCE nor HPT_TRAVERSAL_CULLED", traversal);
     ctx->traversal = traversal;
+    return HPT_OK;
+}
+
+int hpt_set_bvh_build(hpt_ctx* ctx, int build) {
+    if (!ctx) return fail(HPT_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (build != HPT_BVH_BUILD_HOST && build != HPT_BVH_BUILD_GPU)
+        return fail(HPT_ERR_INVALID_ARGUMENT, "build %d is neither HPT_BVH_BUILD_HOST nor HPT_BVH_BUILD_GPU", build);
+    ctx->bvh_build = build;
+    return HPT_OK;
+}
+
+int hpt_scene_build_info(hpt_ctx* ctx, double* gpu_build_ms, uint32_t* num_records, uint32_t* stack_depth) {
+    if (!ctx || !ctx->has_scene) return fail(HPT_ERR_NO_SCENE, "no scene uploaded");
+    if (gpu_build_ms) *gpu_build_ms = ctx->bvh_build == HPT_BVH_BUILD_GPU ? ctx->bvh_build_ms : 0.0;
+    if (num_records) *num_records = ctx->S.num_pairs;
+    if (stack_depth) *stack_depth = ctx->S.stack_depth;
     return HPT_OK;
 }
 

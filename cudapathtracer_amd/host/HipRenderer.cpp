@@ -37,6 +37,7 @@ void HipRenderer::PrepareRender(const Scene& scene) {
         else extra_ctx.push_back(c);
         check(hpt_set_traversal(c, traversal), "hpt_set_traversal");
         check(hpt_set_integrator(c, integrator), "hpt_set_integrator");
+        check(hpt_set_bvh_build(c, scene.flat().gpu_build ? HPT_BVH_BUILD_GPU : HPT_BVH_BUILD_HOST), "hpt_set_bvh_build");
         check(hpt_scene_upload(c, &desc), "hpt_scene_upload");
     }
     framebuffer.assign(num_pixels, Vec3(0.f));

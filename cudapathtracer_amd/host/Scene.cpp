@@ -22,6 +22,8 @@ float luminance(Vec3 c) { return dot(c, Vec3(.2126f, .7152f, .0722f)); }
 void put_int(float* dst, int32_t v) { std::memcpy(dst, &v, 4); }
 }  // namespace
 
+Scene::BvhBuild Scene::default_bvh_build = Scene::BvhBuild::Reference;
+
 // light bookkeeping as common/Scene.hpp:47-56
 void Scene::Add(Sphere* sphere) {
     sphere_owner_.emplace_back(sphere);
@@ -57,6 +59,10 @@ void Scene::buildBVH() {
     if (objects.empty()) throw std::runtime_error("Scene::buildBVH: scene has no meshes");
     query_ctx_.reset();  // intersect() uploads the new scene on its next call
     tri_of_prim_.clear();
+    if (bvh_build == BvhBuild::Gpu) {
+        buildForGpu();
+        return;
+    }
     std::vector<Object*> top_objects;
     for (const ObjectRef& o : objects) top_objects.push_back(o.sphere ? (Object*)spheres[o.index] : (Object*)meshes[o.index]);
     bvh_owner_ = std::make_shared<BVHAccel>(top_objects, 1, BVHAccel::SplitMethod::NAIVE);
@@ -158,6 +164,12 @@ void Scene::buildBVH() {
         }
     }
 
+    fillMaterialsAndLights(*fs);
+    flat_ = fs;
+}
+
+// the material table (one entry per object, Add order) and the light table (emitting meshes, Add order)
+void Scene::fillMaterialsAndLights(FlatScene& fs) const {
     for (size_t obj = 0; obj < objects.size(); ++obj) {
         const Material& m = objects[obj].sphere ? spheres[objects[obj].index]->material : meshes[objects[obj].index]->material;
         hpt_material hm;
@@ -168,17 +180,109 @@ void Scene::buildBVH() {
         hm.metallic = m._metallic;
         hm.roughness = m._roughness;
         hm.ior = m._ior;
-        fs->materials.push_back(hm);
+        fs.materials.push_back(hm);
         if (!objects[obj].sphere && m.emitting()) {
             const int k = objects[obj].index;
             hpt_light L;
             L.area = meshes[k]->area;
             L.root_area = mesh_bvhs[k]->rootArea();
-            L.root_node = (uint32_t)fs->mesh_root[k];
+            L.root_node = (uint32_t)fs.mesh_root[k];
             L.material = (uint32_t)obj;
-            fs->lights.push_back(L);
+            fs.lights.push_back(L);
         }
     }
+}
+
+// BvhBuild::Gpu: triangle records in primitive-id order (objects in Add order, triangles in file order), the
+// node array = the BVHs of the emitting meshes one after the other (what Scene::sampleLight descends,
+// common/BVH.hpp:147-184), leaf words = indices into the triangle array.
+void Scene::buildForGpu() {
+    bvh_owner_.reset();
+    bvh = nullptr;
+    mesh_bvh_owner_.assign(meshes.size(), nullptr);
+    mesh_bvhs.assign(meshes.size(), nullptr);
+    std::vector<int32_t> object_base(objects.size());
+    int32_t base = 0;
+    uint32_t num_nodes = 0;
+    for (size_t k = 0; k < objects.size(); ++k) {
+        object_base[k] = base;
+        if (objects[k].sphere) {
+            base += 1;
+            continue;
+        }
+        const int mi = objects[k].index;
+        MeshTriangle* m = meshes[mi];
+        base += m->num_triangles;
+        if (m->material.emitting()) {
+            std::vector<Object*> tris(m->triangles.size());
+            for (size_t i = 0; i < tris.size(); ++i) tris[i] = &m->triangles[i];
+            mesh_bvh_owner_[mi] = std::make_shared<BVHAccel>(tris, 1, BVHAccel::SplitMethod::NAIVE);
+            mesh_bvhs[mi] = mesh_bvh_owner_[mi].get();
+            num_nodes += (uint32_t)mesh_bvhs[mi]->nodes.size();
+        }
+    }
+    const bool no_lights = num_nodes == 0;
+    if (no_lights) num_nodes = 1;  // the array may not be empty; nothing reads the entry
+    auto fs = std::make_shared<FlatScene>();
+    fs->gpu_build = true;
+    fs->num_nodes = num_nodes;
+    fs->num_tris = (uint32_t)base;
+    fs->nodes.resize(8ull * num_nodes);
+    fs->node_area.resize(num_nodes);
+    fs->tris.resize(16ull * fs->num_tris);
+    fs->tri_v12.resize(8ull * fs->num_tris);
+    fs->prim_of_tri.resize(fs->num_tris);
+    fs->mesh_root.assign(meshes.size(), -1);
+    if (no_lights) {
+        float* n = fs->nodes.data;
+        for (int c = 0; c < 8; ++c) n[c] = 0.f;
+        put_int(n + 3, 1);
+        put_int(n + 7, 0);
+        fs->node_area.data[0] = 0.f;
+    }
+    int32_t g0 = 0;
+    for (size_t obj = 0; obj < objects.size(); ++obj) {
+        const int32_t first = object_base[obj];
+        if (objects[obj].sphere) {
+            const Sphere* sp = spheres[objects[obj].index];
+            float* r = fs->tris.data + 16ull * first;
+            r[0] = sp->center.x; r[1] = sp->center.y; r[2] = sp->center.z; r[3] = 0.f;
+            r[4] = sp->radius; r[5] = sp->radius2; r[6] = 0.f; put_int(r + 7, (int32_t)obj);
+            r[8] = r[9] = r[10] = 0.f; put_int(r + 11, first);
+            r[12] = r[13] = r[14] = 0.f; put_int(r + 15, (int32_t)((uint32_t)obj | 0x80000000u));
+            float* w = fs->tri_v12.data + 8ull * first;
+            for (int c = 0; c < 8; ++c) w[c] = 0.f;
+            fs->prim_of_tri[first] = first;
+            continue;
+        }
+        const int mi = objects[obj].index;
+        const MeshTriangle* mesh = meshes[mi];
+        for (int i = 0; i < mesh->num_triangles; ++i) {
+            const Triangle& T = mesh->triangles[i];
+            const int32_t tri = first + i;
+            float* r = fs->tris.data + 16ull * tri;
+            r[0] = T.v0.x; r[1] = T.v0.y; r[2] = T.v0.z; r[3] = T.area;
+            r[4] = T.e1.x; r[5] = T.e1.y; r[6] = T.e1.z; put_int(r + 7, (int32_t)obj);
+            r[8] = T.e2.x; r[9] = T.e2.y; r[10] = T.e2.z; put_int(r + 11, tri);
+            r[12] = T.normal.x; r[13] = T.normal.y; r[14] = T.normal.z; put_int(r + 15, (int32_t)obj);
+            float* w = fs->tri_v12.data + 8ull * tri;
+            w[0] = T.v1.x; w[1] = T.v1.y; w[2] = T.v1.z; w[3] = 0.f;
+            w[4] = T.v2.x; w[5] = T.v2.y; w[6] = T.v2.z; w[7] = 0.f;
+            fs->prim_of_tri[tri] = tri;
+        }
+        if (!mesh_bvhs[mi]) continue;
+        const std::vector<FlatNode>& mn = mesh_bvhs[mi]->nodes;
+        fs->mesh_root[mi] = g0;
+        for (size_t i = 0; i < mn.size(); ++i) {
+            float* n = fs->nodes.data + 8ull * (g0 + (int32_t)i);
+            const Bounds3& b = mn[i].bounds;
+            n[0] = b.pMin.x; n[1] = b.pMin.y; n[2] = b.pMin.z; put_int(n + 3, g0 + mn[i].miss);
+            n[4] = b.pMax.x; n[5] = b.pMax.y; n[6] = b.pMax.z; put_int(n + 7, mn[i].object >= 0 ? first + mn[i].object : -1);
+            fs->node_area.data[g0 + (int32_t)i] = mn[i].area;
+        }
+        g0 += (int32_t)mn.size();
+    }
+    fillMaterialsAndLights(*fs);
     flat_ = fs;
 }
 
@@ -194,7 +298,7 @@ std::vector<Intersection> Scene::intersect(const std::vector<Ray>& rays) const {
         if (hpt_context_create(query_device, &ctx) != HPT_OK) throw std::runtime_error(std::string("Scene::intersect: ") + hpt_last_error());
         query_ctx_ = std::shared_ptr<hpt_ctx>(ctx, [](hpt_ctx* c) { hpt_context_destroy(c); });
         const hpt_scene_desc d = describe();
-        if (hpt_scene_upload(ctx, &d) != HPT_OK) {
+        if (hpt_set_bvh_build(ctx, f.gpu_build ? HPT_BVH_BUILD_GPU : HPT_BVH_BUILD_HOST) != HPT_OK || hpt_scene_upload(ctx, &d) != HPT_OK) {
             query_ctx_.reset();
             throw std::runtime_error(std::string("Scene::intersect: ") + hpt_last_error());
         }

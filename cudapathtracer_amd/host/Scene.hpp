@@ -31,6 +31,7 @@ struct FlatScene {
     std::vector<int32_t> prim_of_tri;     // leaf order -> global primitive id
     std::vector<int32_t> mesh_root;       // mesh index -> node index of its BVH root
     uint32_t num_nodes = 0, num_tris = 0;
+    bool gpu_build = false;               // Scene::BvhBuild::Gpu: triangles in primitive-id order, nodes = the light meshes' trees only
 };
 
 class Scene {
@@ -67,6 +68,13 @@ public:
         int index;
     };
     std::vector<ObjectRef> objects;
+    // Reference: the two-level BVH by the reference's rules on the host (default; every result the reference's).
+    // Gpu: only the trees of the emitting meshes are built here (Scene::sampleLight descends them); the traversal
+    // records for the whole scene are built on the device at upload (HPT_BVH_BUILD_GPU in include/hpt.h says what
+    // that guarantees).  `bvh` and the mesh_bvhs of non-emitting meshes stay null then.
+    enum class BvhBuild { Reference, Gpu };
+    static BvhBuild default_bvh_build;  // what new scenes start with (the built-in scenes build inside their factory)
+    BvhBuild bvh_build = default_bvh_build;
     void buildBVH();
 
     enum BuiltinScene {
@@ -118,6 +126,8 @@ private:
     std::shared_ptr<BVHAccel> bvh_owner_;
     std::vector<std::shared_ptr<BVHAccel>> mesh_bvh_owner_;
     std::shared_ptr<FlatScene> flat_;
+    void buildForGpu();
+    void fillMaterialsAndLights(FlatScene& fs) const;
     mutable std::shared_ptr<hpt_ctx> query_ctx_;   // intersect(): created and uploaded on first use
     mutable std::vector<int32_t> tri_of_prim_;     // global primitive id -> triangle record
 };

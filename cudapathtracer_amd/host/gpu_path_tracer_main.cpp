@@ -11,6 +11,7 @@
 //   HPT_DEVICE               GPU index (default 0)
 //   HPT_GPUS=N               shard the samples over GPUs 0..N-1 (one RCCL reduce sums the accumulators)
 //   HPT_DEVICES=0,1,3        the same over the GPUs listed (an index may repeat: rehearsal on one GPU)
+//   HPT_BVH=gpu                    build the traversal records on the GPU (median split, one tree for the scene)
 //   HPT_INTEGRATOR=rr,regularize   Russian roulette / path regularisation as the reference writes them (off there)
 //   HPT_SCENE                bunny | glass | heightfield:<n> | file:<scene file> instead of the reference's Cornell box
 #include <cstdlib>
@@ -34,6 +35,8 @@ int main(int argc, char** argv) {
     try {
         // HPT_SCENE=bunny / glass / heightfield:<n> / file:<path> renders another scene than the reference's only one
         const char* which = getenv("HPT_SCENE");
+        if (const char* b = getenv("HPT_BVH"))  // "gpu": traversal records built on the device at upload
+            Scene::default_bvh_build = std::string(b) == "gpu" ? Scene::BvhBuild::Gpu : Scene::BvhBuild::Reference;
         Scene scene = Scene::CreateNamedScene(which ? which : "cornell", maxDepth);
         if (const char* w = getenv("HPT_WIDTH")) scene.width = atoi(w);
         if (const char* h = getenv("HPT_HEIGHT")) scene.height = atoi(h);

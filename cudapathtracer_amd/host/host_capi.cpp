@@ -274,6 +274,24 @@ int hpt_host_render_iterative(const hpt_host_scene* s, int device, int spp, int 
     })
 }
 
+int hpt_host_set_default_bvh_build(int build) {
+    if (build != HPT_BVH_BUILD_HOST && build != HPT_BVH_BUILD_GPU) return fail("build is neither HPT_BVH_BUILD_HOST nor HPT_BVH_BUILD_GPU");
+    Scene::default_bvh_build = build == HPT_BVH_BUILD_GPU ? Scene::BvhBuild::Gpu : Scene::BvhBuild::Reference;
+    return 0;
+}
+
+int hpt_host_scene_set_bvh_build(hpt_host_scene* s, int build) {
+    if (!s) return fail("scene is null");
+    if (build != HPT_BVH_BUILD_HOST && build != HPT_BVH_BUILD_GPU) return fail("build is neither HPT_BVH_BUILD_HOST nor HPT_BVH_BUILD_GPU");
+    s->scene.bvh_build = build == HPT_BVH_BUILD_GPU ? Scene::BvhBuild::Gpu : Scene::BvhBuild::Reference;
+    return 0;
+}
+
+int hpt_host_scene_bvh_build(const hpt_host_scene* s, int* build) {
+    if (!s || !build) return fail("null argument");
+    GUARD(*build = s->scene.flat().gpu_build ? HPT_BVH_BUILD_GPU : HPT_BVH_BUILD_HOST)
+}
+
 int hpt_host_scene_intersect(const hpt_host_scene* s, int device, size_t n, const float* o, const float* d, const uint8_t* shadow,
                             const double* tmax, uint8_t* happened, int32_t* prim, double* distance, float* coords, float* normal,
                             float* triangle_area, int32_t* material_type) {

@@ -170,6 +170,25 @@ int hpt_set_integrator(hpt_ctx* ctx, uint32_t flags);
 #define HPT_TRAVERSAL_CULLED 1
 int hpt_set_traversal(hpt_ctx* ctx, int traversal);
 
+/* Who derives the traversal records (two boxes per record) at the next hpt_scene_upload.
+ *   HPT_BVH_BUILD_HOST (default): from `nodes`, i.e. from the tree the host built by the reference's rules
+ *     (common/BVH.cpp:81-168); every result is the reference's, ties between equal distances included.
+ *   HPT_BVH_BUILD_GPU: on the device, from `tris` / `tri_v12` alone, by the same rule (sort by centroid along
+ *     the longest axis of the centroid bounds, split in the middle) run level by level for all objects at once,
+ *     under a tree over the objects' boxes -- the GPU BVH build the reference's README lists as future work
+ *     (README.md:87).  `tris` need not be in leaf order then: an object is a run of records with the same object
+ *     word (the host side passes primitive-id order), and `nodes` / `node_area` need only hold the trees of the
+ *     emitting meshes (lights[].root_node; Scene::sampleLight descends them), leaf words = indices into `tris`.  The leaf boxes are the reference's and boxes nest, so for rays without a zero
+ *     direction component the triangles tested, every closest distance and every occlusion answer are the
+ *     reference's; when two triangles are hit at bitwise the same distance, the lower index in `tris` is
+ *     reported where the reference reports the one its own tree meets first.  Needs >= 2 primitives.
+ * hpt_scene_build_info: device time of the last GPU build (0 for a host build), number of records, stack
+ * entries a walk can need.  No counterpart in the reference. */
+#define HPT_BVH_BUILD_HOST 0
+#define HPT_BVH_BUILD_GPU 1
+int hpt_set_bvh_build(hpt_ctx* ctx, int build);
+int hpt_scene_build_info(hpt_ctx* ctx, double* gpu_build_ms, uint32_t* num_records, uint32_t* stack_depth);
+
 /* thrust::fill(framebuffer, 0) of CudaRenderer::Render (gpu_path_tracer/CudaRenderer.cu:56).
  * accum_dev = NULL clears the context's own buffer. */
 int hpt_accum_clear(hpt_ctx* ctx, int64_t* accum_dev, void* stream);

@@ -76,6 +76,13 @@ int hpt_host_render_iterative(const hpt_host_scene* s, int device, int spp, int 
  * onto devices[0].  iterative != 0: through PathTrace, sample iter on entry iter mod num_devices. */
 int hpt_host_render_devices(const hpt_host_scene* s, const int* devices, int num_devices, int spp, int max_depth,
                             int num_threads, int mode, int iterative, float* rgb, hpt_stats* stats);
+/* Scene::default_bvh_build: scenes created from now on flatten for HPT_BVH_BUILD_HOST (default) or HPT_BVH_BUILD_GPU
+ * (include/hpt.h); the renderer picks the matching upload. */
+int hpt_host_set_default_bvh_build(int build);
+/* Scene::bvh_build of one scene (takes effect at its next hpt_host_scene_build), and how the scene was last built */
+int hpt_host_scene_set_bvh_build(hpt_host_scene* s, int build);
+int hpt_host_scene_bvh_build(const hpt_host_scene* s, int* build);
+
 /* Scene::intersect (common/Scene.hpp:95-97) on a batch of rays, run on GPU `device` (hpt_intersect_batch on a context the
  * scene keeps).  shadow[i] != 0 = any-hit query against tmax[i] (Ray::shadowTest / shadowDistance).  Outputs (each may be
  * NULL) are the fields of Intersection (common/Intersection.hpp:14-35): happened, distance, coords = ray(distance), normal,

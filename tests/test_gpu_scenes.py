@@ -537,3 +537,93 @@ def test_host_scene_intersect_equals_oracle(hp, oracle):
     one = sc.intersect(o[:1], d[:1])
     assert one["prim"][0] == want_p[0] and one["distance"][0] == want_t[0]
     assert len(sc.intersect(np.zeros((0, 3)), np.zeros((0, 3)))["prim"]) == 0
+
+
+def _hits_equal_up_to_ties(got, want, what):
+    """Closest hits of a tree other than the reference's over the same leaf boxes: every distance is the
+    reference's bit for bit; the primitive may differ only where two are hit at that very distance."""
+    gp, gt = got
+    wp, wt = want
+    assert np.array_equal(gt.view(np.int64), wt.view(np.int64)), "%s: %d distances differ" % (what, (gt != wt).sum())
+    assert np.array_equal(gp >= 0, wp >= 0)
+    return int((gp != wp).sum())
+
+
+@pytest.mark.parametrize("name", ["bunny", "heightfield128", "heightfield8", "spheres"])
+def test_gpu_bvh_build(hp, oracle, gpu_ctx, name):
+    """hpt_set_bvh_build(HPT_BVH_BUILD_GPU): the traversal records are built on the device from the triangle array
+    (median split by centroid, level by level, one tree for the scene; the host builds only the light's tree).
+    Closest distances, occlusion answers, ray counters and rendered images equal the oracle's bit for bit; a
+    primitive id may differ only between triangles hit at bitwise the same distance."""
+    from cudapathtracer_amd import scenes
+    w, h, depth, spp = 56, 40, 6, 2
+    if name == "spheres":
+        sc, osc = _sphere_scene(hp, oracle, w, h, depth, big=True)
+        sc.buildBVH(gpu=True)
+    else:
+        parts = scenes.bunny_in_cornell_parts() if name == "bunny" else scenes.heightfield_in_cornell_parts(int(name[11:]))
+        sc = hp.Scene(w, h, camPos=scenes.CORNELL_CAM, fov=40.0, maxDepth=depth)
+        for _, tris, mat in parts:
+            sc.Add(tris, hp.Material(**mat))
+        sc.buildBVH(gpu=True)
+        osc = _oracle_scene(oracle, parts, w, h)
+    assert sc.gpu_build
+    fa = sc.flat_arrays()
+    assert np.array_equal(fa["prim_of_tri"], np.arange(len(fa["prim_of_tri"])))  # primitive-id order
+    gpu_ctx.upload(sc)
+    info = gpu_ctx.build_info()
+    assert info["records"] == len(fa["prim_of_tri"]) - 1 and info["gpu_build_ms"] > 0 and 1 <= info["stack_depth"] <= 40
+    assert gpu_ctx.stats()["variant"] in (5, 6)
+    ties = 0
+    o, d = primary_rays(192, 192, scenes.CORNELL_CAM, osc.info()["cam_scale"])
+    ties += _hits_equal_up_to_ties(gpu_ctx.intersect(o, d), osc.intersect(o, d), "primary")
+    o, d = random_rays(1 << 17, 41)
+    ties += _hits_equal_up_to_ties(gpu_ctx.intersect(o, d), osc.intersect(o, d), "random")
+    assert ties <= 4, "%d primitive ids differ at equal distances" % ties
+    _same_occlusion(gpu_ctx, osc, *_shadow_batch(1 << 16, 42, down=name.startswith("heightfield")))
+    want_acc, ost = osc.render(RNG_PHILOX, TRIG_PORTABLE, depth, spp, fixed=True)
+    for mode in (1, 2):
+        gpu_ctx.stats_reset()
+        gpu_ctx.accum_clear()
+        gpu_ctx.render(mode, 256, depth, 0, spp)
+        got = gpu_ctx.resolve(spp)
+        st = gpu_ctx.stats()
+        assert (st["closest_queries"], st["shadow_queries"]) == (ost["closest_queries"], ost["shadow_queries"])
+        assert np.array_equal(got.view(np.int32), oracle.resolve(want_acc, spp).view(np.int32)), "mode %d" % mode
+    # the host build of the same scene object gives the reference's tree again
+    sc.buildBVH(gpu=False)
+    assert not sc.gpu_build
+    gpu_ctx.upload(sc)
+    assert gpu_ctx.build_info()["gpu_build_ms"] == 0
+    _same_hits(gpu_ctx, osc, *random_rays(1 << 14, 43))
+
+
+def test_gpu_bvh_build_of_the_million_triangle_scene(hp, gpu_ctx):
+    """The 1.0 M-triangle height field with its records built on the device: the build takes milliseconds, and
+    closest hits / occlusion answers equal those of the host-built reference tree on the same GPU."""
+    import time
+    t0 = time.time()
+    sc_gpu = hp.Scene.CreateNamedScene("heightfield:708", 5, 64, 64, bvh_build=hp.BVH_BUILD_GPU)
+    t_gpu_host_part = time.time() - t0
+    gpu_ctx.upload(sc_gpu)
+    info = gpu_ctx.build_info()
+    assert info["records"] == len(sc_gpu.flat_arrays()["prim_of_tri"]) - 1 > 1_000_000
+    assert 0 < info["gpu_build_ms"] < 500, info
+    o, d = random_rays(1 << 18, 51)
+    so, sd, sh, tm = _shadow_batch(1 << 17, 52, down=True)
+    got = gpu_ctx.intersect(o, d)
+    got_s = gpu_ctx.intersect(so, sd, sh, tm)
+    gpu_ctx.accum_clear()
+    gpu_ctx.render(2, 256, 5, 0, 1)
+    img_gpu = gpu_ctx.accum_download()
+    sc_ref = hp.Scene.CreateNamedScene("heightfield:708", 5, 64, 64)
+    gpu_ctx.upload(sc_ref)
+    want = gpu_ctx.intersect(o, d)
+    want_s = gpu_ctx.intersect(so, sd, sh, tm)
+    # primitive ids: the reference tree reports leaf-order-mapped global ids; both are global primitive ids
+    assert _hits_equal_up_to_ties(got, want, "1M random") <= 8
+    assert np.array_equal(got_s[0] >= 0, want_s[0] >= 0)
+    gpu_ctx.accum_clear()
+    gpu_ctx.render(2, 256, 5, 0, 1)
+    assert np.array_equal(img_gpu, gpu_ctx.accum_download())
+    print("host part of the GPU-build scene %.2f s, device build %.2f ms" % (t_gpu_host_part, info["gpu_build_ms"]))

@@ -9,7 +9,7 @@ FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fno-fast-ma
 pids=()
 for spec in "$@"; do
   tag=${spec%%:*}; defs=${spec#*:}
-  /opt/rocm/bin/hipcc $FLAGS $defs -shared -o build/tune/libhpt_$tag.so cudapathtracer_amd/csrc/hpt_core.hip &
+  /opt/rocm/bin/hipcc $FLAGS $defs -shared -o build/tune/libhpt_$tag.so cudapathtracer_amd/csrc/hpt_core.hip cudapathtracer_amd/csrc/hpt_bvh_build.hip &
   pids+=($!)
   if [ ${#pids[@]} -ge 4 ]; then wait ${pids[0]}; pids=("${pids[@]:1}"); fi
 done
