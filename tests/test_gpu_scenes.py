@@ -374,6 +374,11 @@ def test_cli_renders_the_large_scene_configurations(tmp_path):
         assert data.startswith(b"P6\n%s %s\n255\n" % (res.encode(), res.encode())) and len(data) > 3 * int(res) ** 2
         body = np.frombuffer(data[-3 * int(res) ** 2:], np.uint8)
         assert body.max() == 255 and 20 < body.mean() < 200
+        # HPT_BVH=gpu: the same picture from traversal records built on the device
+        r = subprocess.run([os.path.join(root, "build", "gpu_path_tracer"), "4", "20", "256", "2"], cwd=str(tmp_path), env=dict(env, HPT_BVH="gpu"),
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=110)
+        assert r.returncode == 0, r.stdout
+        assert (tmp_path / "out" / "gpu" / (name + ".ppm")).read_bytes() == data
 
 
 @pytest.mark.parametrize("name", ["cornell", "heightfield4", "heightfield8", "bunny"])
