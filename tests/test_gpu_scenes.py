@@ -632,3 +632,55 @@ def test_gpu_bvh_build_of_the_million_triangle_scene(hp, gpu_ctx):
     gpu_ctx.render(2, 256, 5, 0, 1)
     assert np.array_equal(img_gpu, gpu_ctx.accum_download())
     print("host part of the GPU-build scene %.2f s, device build %.2f ms" % (t_gpu_host_part, info["gpu_build_ms"]))
+
+
+@pytest.mark.parametrize("name", ["no_light", "degenerate", "two_triangles", "many_objects", "one_triangle"])
+def test_gpu_bvh_build_edges(hp, oracle, gpu_ctx, name):
+    """The device-side build at the edges of the scene description: no emitter (no sampling tree at all), zero-area
+    triangles (NaN normals, NaN-free boxes), the smallest scene it accepts, a scene of many small objects (the tree
+    over the objects carries most of the work), and the one it refuses (a single primitive)."""
+    from cudapathtracer_amd import scenes
+    light = dict(type=0, emission=scenes.light_emission())
+    quad = np.array([[[100, 500, 100], [400, 500, 100], [400, 500, 400]],
+                     [[100, 500, 100], [400, 500, 400], [100, 500, 400]]], np.float32)[:, ::-1]
+    if name == "no_light":
+        parts = [("a", _soup(5, 1), scenes.WHITE), ("b", _soup(3, 2), scenes.METAL)]
+    elif name == "degenerate":
+        t = _soup(6, 3)
+        t[1, 2] = t[1, 1]
+        t[4] = t[4, 0]
+        parts = [("light", quad, light), ("a", t, scenes.WHITE)]
+    elif name == "two_triangles":
+        parts = [("light", quad, light)]
+    elif name == "one_triangle":
+        parts = [("light", quad[:1], light)]
+    else:
+        parts = [("light", quad, light)] + [("o%d" % k, _soup(1 + k % 5, 100 + k, size=60.0), scenes.WHITE if k % 2 else scenes.METAL) for k in range(37)]
+    w, h, depth, spp = 24, 16, 4, 3
+    sc = hp.Scene(w, h, camPos=scenes.CORNELL_CAM, fov=40.0, maxDepth=depth)
+    for _, tris, mat in parts:
+        sc.Add(tris, hp.Material(**mat))
+    sc.buildBVH(gpu=True)
+    if name == "one_triangle":
+        with pytest.raises(hp.HptError, match="at least two primitives"):
+            gpu_ctx.upload(sc)
+        return
+    osc = _oracle_scene(oracle, parts, w, h)
+    gpu_ctx.upload(sc)
+    assert gpu_ctx.stats()["variant"] == 6 and gpu_ctx.build_info()["records"] == sum(len(p[1]) for p in parts) - 1
+    o, d = primary_rays(64, 64, scenes.CORNELL_CAM, osc.info()["cam_scale"])
+    assert _hits_equal_up_to_ties(gpu_ctx.intersect(o, d), osc.intersect(o, d), "primary") == 0
+    assert _hits_equal_up_to_ties(gpu_ctx.intersect(*random_rays(1 << 14, 61)), osc.intersect(*random_rays(1 << 14, 61)), "random") == 0
+    _same_occlusion(gpu_ctx, osc, *_shadow_batch(1 << 13, 62))
+    want_acc, ost = osc.render(RNG_PHILOX, TRIG_PORTABLE, depth, spp, fixed=True)
+    for mode in (1, 2):
+        gpu_ctx.stats_reset()
+        gpu_ctx.accum_clear()
+        gpu_ctx.render(mode, 64, depth, 0, spp)
+        st = gpu_ctx.stats()
+        assert (st["closest_queries"], st["shadow_queries"]) == (ost["closest_queries"], ost["shadow_queries"])
+        assert np.array_equal(gpu_ctx.resolve(spp).view(np.int32), oracle.resolve(want_acc, spp).view(np.int32)), "mode %d" % mode
+    # the entry point that allocates nothing runs on the device-built records as well
+    gpu_ctx.accum_clear()
+    gpu_ctx.render_static(2, 64, depth, 0, spp)
+    assert np.array_equal(gpu_ctx.resolve(spp).view(np.int32), oracle.resolve(want_acc, spp).view(np.int32))
