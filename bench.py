@@ -95,7 +95,7 @@ def cpu_baseline(scene, width, height, depth, spp):
             scene, width, height, depth, spp, rays / 1e6, dt, spp / dt),
         "spp_per_sec": spp / dt,
         "relation_to_reference": "the restatement renders the reference's image bit for bit and runs 1.09-1.15x as fast as the "
-                                 "compiled reference on the same cores (BASELINE.md)",
+                                 "compiled reference on the same 8 cores (512x512 16 spp depth 5: 7.50 s vs 8.66 s; 1024x1024 16 spp depth 20: 38.9 s vs 42.5 s)",
     }, {"box_per_ray": st["box_tests"] / rays, "tri_per_ray": st["tri_tests"] / rays,
         "rays_per_path": rays / st["paths"]}
 

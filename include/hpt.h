@@ -286,7 +286,8 @@ int hpt_accum_download(hpt_ctx* ctx, const int64_t* accum_dev, int64_t* accum_ho
  * contexts must hold scenes of one resolution.  Waits for the contexts' queued renders and for the
  * reduce.  The other contexts' buffers are left in an unspecified state (clear them before reuse).
  * One process drives all devices (one host thread per device for the renders); processes that own
- * one GPU each reduce hpt_accum_buffer() with their own communicator instead. */
+ * one GPU each reduce hpt_accum_buffer() with their own communicator instead (torch.distributed / RCCL:
+ * cudapathtracer_amd/sharding.py). */
 int hpt_accum_reduce(hpt_ctx* const* ctxs, int n, int root);
 
 /* Host-only (no GPU, no context): the nine per-octant node-array copies that hpt_scene_upload
