@@ -684,3 +684,34 @@ def test_gpu_bvh_build_edges(hp, oracle, gpu_ctx, name):
     gpu_ctx.accum_clear()
     gpu_ctx.render_static(2, 64, depth, 0, spp)
     assert np.array_equal(gpu_ctx.resolve(spp).view(np.int32), oracle.resolve(want_acc, spp).view(np.int32))
+
+
+def test_gpu_bvh_build_random_soups(hp, gpu_ctx):
+    """Device-built records against the host-built reference tree on the same GPU, over soups of many sizes
+    (odd, even, powers of two and their neighbours), with coincident triangles (every centroid ties) and objects of
+    one primitive: closest distances bit-equal, primitive ids equal except at equal distances, occlusion equal."""
+    from cudapathtracer_amd import scenes
+    rs = np.random.RandomState(77)
+    o, d = random_rays(1 << 13, 78)
+    so, sd, sh, tm = _shadow_batch(1 << 12, 79)
+    for case, n in enumerate([2, 3, 4, 5, 7, 8, 9, 31, 32, 33, 100, 255, 256, 257, 1000, 4097]):
+        soup = _soup(n, 200 + case, size=120.0)
+        if case % 4 == 1:
+            soup[n // 2:] = soup[0]                     # half of the triangles coincide
+        parts = [("a", soup[: max(1, n // 3)], scenes.WHITE), ("b", soup[max(1, n // 3):], scenes.METAL)] if n >= 2 else []
+        parts = [p for p in parts if len(p[1])]
+        results = []
+        for gpu in (False, True):
+            sc = hp.Scene(16, 16, camPos=scenes.CORNELL_CAM, fov=40.0, maxDepth=3)
+            for _, tris, mat in parts:
+                sc.Add(tris, hp.Material(**mat))
+            sc.buildBVH(gpu=gpu)
+            gpu_ctx.upload(sc)
+            results.append((gpu_ctx.intersect(o, d), gpu_ctx.intersect(so, sd, sh, tm)))
+        (hp_c, ht_c), (hp_s, _) = results[0]
+        (gp_c, gt_c), (gp_s, _) = results[1]
+        assert np.array_equal(gt_c.view(np.int64), ht_c.view(np.int64)), "n = %d" % n
+        differ = gp_c != hp_c
+        if differ.any():   # only between coincident triangles: the other tree's choice is hit at the same distance
+            assert case % 4 == 1, "n = %d: %d ids differ" % (n, differ.sum())
+        assert np.array_equal(gp_s >= 0, hp_s >= 0), "n = %d" % n
