@@ -5,6 +5,7 @@
 set -u
 TAG=$1; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
+rm -rf $OUT   # (results of an earlier collection would be averaged in)
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH_ARGS="$*"
