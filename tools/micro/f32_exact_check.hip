@@ -1,6 +1,8 @@
 // Exhaustive search harness: which short instruction sequences give the correctly rounded
 // 1.0f / x and sqrtf(x) for EVERY float in the guarded range (others take the compiler's sequence)?
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -o f32_exact_check f32_exact_check.hip
+// (A search harness over candidate sequences; the regression check of the two that hpt_device.h uses, compiled
+// from that header, is tools/micro/exact_math_check.hip.)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>

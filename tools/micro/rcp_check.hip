@@ -1,6 +1,8 @@
 // Exhaustive check of reciprocal_of_float (cudapathtracer_amd/csrc/hpt_device.h) against the IEEE
 // double division 1. / (double)x for EVERY float x (all 2^32 bit patterns).
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I../../cudapathtracer_amd/csrc -o rcp_check rcp_check.hip
+// (Kept as the stand-alone derivation of the sequence; the regression check that compiles the function from
+// hpt_device.h itself is tools/micro/exact_math_check.hip.)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
