@@ -330,3 +330,24 @@ def test_error_paths(hp, gpu_ctx):
     gpu_ctx.render(1, 256, 0, 0, 4)
     gpu_ctx.render(2, 256, 5, 0, 0)
     assert not gpu_ctx.resolve(1).any()
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_full_resolution_render_matches_oracle_bit_exact(hp, oracle, gpu_ctx, mode):
+    """The benchmark's resolution and depth (Cornell 1024 x 1024, depth 20) at 4 spp: 49 M rays per mode, every
+    accumulator and both ray counters equal the oracle's -- a soak over the rarely taken branches (exact fallbacks of
+    the triangle classification, axis-parallel rays, NaN resets) that the small images cannot reach."""
+    w = h = 1024
+    depth, spp = 20, 4
+    sc = hp.Scene.CreateBuiltinScene(hp.Scene.CornellBox, depth, w, h)
+    osc = oracle.cornell(w, h)
+    gpu_ctx.upload(sc)
+    gpu_ctx.stats_reset()
+    gpu_ctx.accum_clear()
+    gpu_ctx.render(mode, 256, depth, 0, spp)
+    got = gpu_ctx.accum_download()
+    st = gpu_ctx.stats()
+    want, ost = osc.render(RNG_PHILOX, TRIG_PORTABLE, depth, spp, fixed=True)
+    assert (st["closest_queries"], st["shadow_queries"]) == (ost["closest_queries"], ost["shadow_queries"])
+    bad = np.flatnonzero((got != want).any(axis=1))
+    assert bad.size == 0, "%d of %d pixels differ" % (bad.size, w * h)

@@ -715,3 +715,29 @@ def test_gpu_bvh_build_random_soups(hp, gpu_ctx):
         if differ.any():   # only between coincident triangles: the other tree's choice is hit at the same distance
             assert case % 4 == 1, "n = %d: %d ids differ" % (n, differ.sum())
         assert np.array_equal(gp_s >= 0, hp_s >= 0), "n = %d" % n
+
+
+@pytest.mark.parametrize("gpu_build", [False, True])
+def test_bunny_full_resolution_render_matches_oracle_bit_exact(hp, oracle, gpu_ctx, gpu_build):
+    """The bunny configuration at its benchmark resolution and depth (1024 x 1024, depth 20, streamed mode under the
+    wave scheduler), 1 spp = 11 M rays: every accumulator and both ray counters equal the oracle's, on the host-built
+    tree and on device-built records."""
+    from cudapathtracer_amd import scenes
+    parts = scenes.bunny_in_cornell_parts()
+    w = h = 1024
+    depth, spp = 20, 1
+    sc = hp.Scene(w, h, camPos=scenes.CORNELL_CAM, fov=40.0, maxDepth=depth)
+    for _, tris, mat in parts:
+        sc.Add(tris, hp.Material(**mat))
+    sc.buildBVH(gpu=gpu_build)
+    osc = _oracle_scene(oracle, parts, w, h)
+    gpu_ctx.upload(sc)
+    gpu_ctx.stats_reset()
+    gpu_ctx.accum_clear()
+    gpu_ctx.render(2, 256, depth, 0, spp)
+    got = gpu_ctx.accum_download()
+    st = gpu_ctx.stats()
+    want, ost = osc.render(RNG_PHILOX, TRIG_PORTABLE, depth, spp, fixed=True)
+    assert (st["closest_queries"], st["shadow_queries"]) == (ost["closest_queries"], ost["shadow_queries"])
+    bad = np.flatnonzero((got != want).any(axis=1))
+    assert bad.size == 0, "%d of %d pixels differ" % (bad.size, w * h)
