@@ -463,8 +463,11 @@ __global__ void k_wf_generate(DevScene S, uint32_t s_begin, uint64_t first, uint
 // (int64 atomics).  Survivors are compacted with __ballot + prefix popcount and one LDS atomic
 // per wave.  Segments are independent, so the bounce loop runs inside the kernel with workgroup
 // barriers only: one launch per batch, the scene staged once, no workgroup waits for another.
+#ifndef HPT_WF_WAVES
+#define HPT_WF_WAVES 1
+#endif
 template <int kScene, bool kExt>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, HPT_WF_WAVES)
 k_wf_bounces(DevScene S, int max_depth, uint32_t seg, WfQueue q0, WfQueue q1, const uint32_t* __restrict__ live,
              int64_t* __restrict__ accum, unsigned long long* __restrict__ stats) {
     extern __shared__ float4 lds[];
