@@ -10,7 +10,8 @@
 // has no /root/reference.  Nothing in cudapathtracer_amd/ builds, links or runs it.
 //
 // Environment (not in the reference): HPT_MODELS_DIR (default "models"), HPT_WIDTH / HPT_HEIGHT
-// (default 512 x 512, common/Scene.cpp:29), HPT_OUT_DIR (default "out/cpu").
+// (default 512 x 512, common/Scene.cpp:29), HPT_OUT_DIR (default "out/cpu"), HPT_PFM=1 (also write the linear
+// radiance as <scene name>.pfm).
 #include <sys/stat.h>
 
 #include <chrono>
@@ -80,6 +81,13 @@ int main(int argc, char** argv) {
     ::mkdir("out", 0777);
     ::mkdir(dir.c_str(), 0777);
     if (!save_ppm(dir + "/Cornell Box.ppm", framebuffer, width, height)) return 1;
+    if (std::getenv("HPT_PFM")) {  // linear radiance, rows bottom to top, little-endian floats (what tools/image_diff.py reads)
+        FILE* fp = std::fopen((dir + "/Cornell Box.pfm").c_str(), "wb");
+        if (!fp) return 1;
+        std::fprintf(fp, "PF\n%d %d\n-1.0\n", width, height);
+        for (int y = height - 1; y >= 0; --y) std::fwrite(&framebuffer[(size_t)3 * y * width], sizeof(float), (size_t)3 * width, fp);
+        std::fclose(fp);
+    }
 
     const double seconds = std::chrono::duration_cast<std::chrono::milliseconds>(stop - start).count() / 1000.0;
     std::cout << "Render complete: \n";

@@ -97,3 +97,28 @@ def test_converged_image_matches_the_reference_renderer(hp, gpu_ctx, mode):
     def down(a):
         return np.clip(a, 0, 1).reshape(12, 8, 12, 8, 3).mean((1, 3))
     assert np.sqrt(((down(img) - down(ref_a)) ** 2).mean()) < 0.30 * noise
+
+
+def test_gpu_path_tracer_picture_against_cpu_path_tracer(tmp_path):
+    """north_star's image check through the two command-line programs: build/gpu_path_tracer (1024 spp) against
+    oracle/cpu_path_tracer (64 spp, the reference's random stream and libm: the picture the reference's own CPU
+    program renders), Cornell box 128 x 128, depth 20, compared by tools/image_diff.py on the linear radiance.
+    Bar: RMSE of the values clamped to [0, 1] <= 0.13 -- the 64-spp CPU picture's own noise (two independent 64-spp
+    reference renders differ by 0.1425 at 96 x 96, tests/golden/cornell_images.npz; one of them against a converged
+    picture by 1/sqrt(2) of that) -- and channel means within 2 %."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HPT_MODELS_DIR=os.path.join(root, "models"), HPT_WIDTH="128", HPT_HEIGHT="128", HPT_PFM="1")
+    (tmp_path / "out" / "gpu").mkdir(parents=True)
+    for exe, args in ((os.path.join(root, "build", "gpu_path_tracer"), ["1024", "20", "256", "1"]),
+                      (os.path.join(root, "oracle", "cpu_path_tracer"), ["64", "20", "16"])):
+        r = subprocess.run([exe] + args, cwd=str(tmp_path), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=110)
+        assert r.returncode == 0, r.stdout
+    import json
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "image_diff.py"), str(tmp_path / "out" / "gpu" / "Cornell Box.pfm"),
+                        str(tmp_path / "out" / "cpu" / "Cornell Box.pfm"), "--max-rmse-clamped", "0.13", "--json"], stdout=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stdout
+    d = json.loads(r.stdout)
+    assert d["width"] == d["height"] == 128 and 0.02 < d["rmse_clamped"] <= 0.13, d
+    assert np.abs(np.array(d["mean_a"]) / np.array(d["mean_b"]) - 1).max() < 0.02, d

@@ -5,6 +5,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -545,3 +546,22 @@ def test_host_rng_equals_the_reference_stream(hp):
     g = np.load(os.path.join(G, "cornell_shading.npz"))
     assert np.array_equal(hp.rng_floats(3, 12345, 64).view(np.uint32), g["rng_k3_m12345"].view(np.uint32))
     assert np.array_equal(hp.rng_floats(0, 0, 64).view(np.uint32), g["rng_k0_m0"].view(np.uint32))
+
+
+def test_image_diff_tool(hp, tmp_path):
+    """tools/image_diff.py on PFM (linear radiance) and PPM (tone-mapped) files written by the host library."""
+    rs = np.random.RandomState(5)
+    a = (rs.rand(12 * 8, 3) * 1.5).astype(np.float32)
+    b = a.copy()
+    b[7] += np.float32(0.25)
+    for name, img in (("a", a), ("b", b)):
+        hp.SavePFM(str(tmp_path / (name + ".pfm")), img, 12, 8)
+        hp.SavePPM(str(tmp_path / (name + ".ppm")), img, 12, 8)
+    tool = os.path.join(ROOT, "tools", "image_diff.py")
+    r = subprocess.run([sys.executable, tool, str(tmp_path / "a.pfm"), str(tmp_path / "a.pfm")], capture_output=True, text=True)
+    assert r.returncode == 0 and "identical" in r.stdout and "rmse 0 " in r.stdout
+    r = subprocess.run([sys.executable, tool, str(tmp_path / "a.pfm"), str(tmp_path / "b.pfm"), "--max-rmse-clamped", "1e-4"], capture_output=True, text=True)
+    want = np.sqrt(np.mean((a.astype(np.float64) - b) ** 2))
+    assert r.returncode == 1 and "1 of 96 pixels differ" in r.stdout and ("rmse %.6g" % want) in r.stdout
+    r = subprocess.run([sys.executable, tool, str(tmp_path / "a.ppm"), str(tmp_path / "b.ppm")], capture_output=True, text=True)
+    assert r.returncode == 0 and "1 of 96 pixels differ" in r.stdout
