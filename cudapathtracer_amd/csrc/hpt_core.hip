@@ -199,6 +199,11 @@ __device__ __forceinline__ void accumulate_pixel(int64_t* accum, uint32_t pixel,
 // Waves per SIMD the single-kernel variant is compiled for.  4 = 118 VGPRs, no spills.  The
 // kernel is VALU-issue bound: builds for 3 and for 5 waves (the latter spills to scratch) run
 // within 2 % of it.
+// Camera directions of the single-kernel mode are generated a whole wave at a time into a ring of 128 entries per wave
+// (3 floats each) and handed to lanes as their paths end: generating them where they are needed costs a Philox block,
+// two divisions and a normalisation for the five or six lanes of a wave that need a new path in a given iteration.
+constexpr uint32_t kCamRingWords = 128u * 3u;
+
 #ifndef HPT_MEGA_WAVES
 #define HPT_MEGA_WAVES 4
 #endif
@@ -229,7 +234,9 @@ k_render_mega(DevScene S, int max_depth, uint32_t s_begin_all, uint32_t s_count_
 #else
     const uint32_t prof_words = 0u;
 #endif
-    const TriQueue tq = make_tri_queue<kScene>(reinterpret_cast<uint32_t*>(lds + S.lds_float4s) + waves_per_block * 768u + prof_words);
+    uint32_t* const behind_acc = reinterpret_cast<uint32_t*>(lds + S.lds_float4s) + waves_per_block * 768u + prof_words;
+    float* const cam_ring = reinterpret_cast<float*>(behind_acc) + wave * kCamRingWords;
+    const TriQueue tq = make_tri_queue<kScene>(behind_acc + waves_per_block * kCamRingWords);
     stage_scene<kScene>(S, lds);
 
     const uint32_t W = (uint32_t)S.width, H = (uint32_t)S.height;
@@ -251,6 +258,7 @@ k_render_mega(DevScene S, int max_depth, uint32_t s_begin_all, uint32_t s_count_
     uint32_t old_x0 = 0, old_y0 = 0, old_vw = 1, old_nv = 0;
     bool cur_open = false, old_open = false, queue_empty = false;
     uint32_t gen = 0;  // accumulator of `cur`; `old` uses the other one
+    uint32_t ring_end = 0;  // items [.., ring_end) of `cur` have their camera directions in the ring (entry = item mod 128)
     // per lane: closest queries in the low, shadow queries in the high 16 bits of one register,
     // added to the global counters whenever the wave opens a unit (a wave runs at most
     // (s_chunk + 2) * max_depth <= 65535 loop iterations between two openings, checked by the host)
@@ -299,6 +307,7 @@ k_render_mega(DevScene S, int max_depth, uint32_t s_begin_all, uint32_t s_count_
                         // u < n_units = tiles * ceil(s_count_all / s_chunk): the chunk starts inside the range
                         cur_total = cur_nv * min(s_chunk, s_count_all - chunk * s_chunk);
                         cur_next = 0;
+                        ring_end = 0;
                         cur_open = true;
                         n_paths_wave += cur_total;  // every item of a pool is traced
                     } else {
@@ -307,22 +316,50 @@ k_render_mega(DevScene S, int max_depth, uint32_t s_begin_all, uint32_t s_count_
                 }
             }
             if (cur_open && cur_next < cur_total) {
+                // item k of the pool = (pixel slot, sample) of the unit
+                auto item = [&](uint32_t k, uint32_t& sl, uint32_t& pixel, uint32_t& sample) {
+                    uint32_t px, py, smp;
+                    if (cur_nv == 64u) {  // full tile (wave-uniform): no integer divisions
+                        sl = k & 63u;
+                        smp = k >> 6;
+                        px = sl & 7u;
+                        py = sl >> 3;
+                    } else {
+                        sl = k % cur_nv;
+                        smp = k / cur_nv;
+                        px = sl % cur_vw;
+                        py = sl / cur_vw;
+                    }
+                    pixel = (cur_y0 + py) * W + cur_x0 + px;
+                    sample = cur_s0 + smp;
+                };
+                // the lanes to refill take at most wave_lanes items: have their directions in the ring.  A batch is
+                // generated only when fewer than wave_lanes items are ahead, so ring_end stays below cur_next + 128
+                // and no entry is overwritten before its item has been handed out.
+                const uint32_t want_end = min(cur_total, cur_next + wave_lanes);
+                while (ring_end < want_end) {
+                    const uint32_t kk = ring_end + lane;
+                    if (kk < cur_total) {
+                        uint32_t sl, pixel, sample;
+                        item(kk, sl, pixel, sample);
+                        const f3 dir = camera_direction(S, pixel, sample);
+                        float* e = cam_ring + 3u * (kk & 127u);
+                        e[0] = dir.x;
+                        e[1] = dir.y;
+                        e[2] = dir.z;
+                    }
+                    ring_end += wave_lanes;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the ring is read by other lanes of the wave
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 const uint32_t k = cur_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
                 cur_next = min(cur_total, cur_next + (uint32_t)__popcll(need));
                 if (!alive && k < cur_total) {
-                    uint32_t px, py, smp;
-                    if (cur_nv == 64u) {  // full tile (wave-uniform): no integer divisions
-                        slot = k & 63u;
-                        smp = k >> 6;
-                        px = slot & 7u;
-                        py = slot >> 3;
-                    } else {
-                        slot = k % cur_nv;
-                        smp = k / cur_nv;
-                        px = slot % cur_vw;
-                        py = slot / cur_vw;
-                    }
-                    generate_camera_path(S, (cur_y0 + py) * W + cur_x0 + px, cur_s0 + smp, p);
+                    uint32_t pixel, sample;
+                    item(k, slot, pixel, sample);
+                    const float* e = cam_ring + 3u * (k & 127u);
+                    start_camera_path(S, pixel, sample, mk(e[0], e[1], e[2]), p);
                     lane_gen = gen;
                     alive = true;
                 }
@@ -883,7 +920,7 @@ k_render_mega_sm(DevScene S, int max_depth, uint32_t s_begin_all, uint32_t s_cou
     // two accumulators (unit generations 0 / 1) of 64 pixels x RGB per wave
     unsigned long long* tile_acc = reinterpret_cast<unsigned long long*>(lds + S.lds_float4s) + wave * 384u;
     for (uint32_t i = lane; i < 384u; i += wave_lanes) tile_acc[i] = 0ull;
-    const TriQueue tq = make_tri_queue<kScene>(reinterpret_cast<uint32_t*>(lds + S.lds_float4s) + waves_per_block * 768u);
+    const TriQueue tq = make_tri_queue<kScene>(reinterpret_cast<uint32_t*>(lds + S.lds_float4s) + waves_per_block * (768u + kCamRingWords));  // (same layout as k_render_mega; the ring is not used here)
     stage_scene<kScene>(S, lds);
     const uint32_t W = (uint32_t)S.width, H = (uint32_t)S.height;
     const uint32_t tiles_x = (W + 7u) >> 3;
@@ -1496,7 +1533,7 @@ int render_launch(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sam
 
     if (mode == HPT_MODE_SINGLE_KERNEL) {
         const uint32_t waves_per_block = ((uint32_t)block + 63u) >> 6;
-        uint32_t lds_mega = lds + waves_per_block * 384u * 8u + (lds_bytes(S, block) - lds);  // + two tile accumulators per wave + queues
+        uint32_t lds_mega = lds + waves_per_block * (384u * 8u + kCamRingWords * 4u) + (lds_bytes(S, block) - lds);  // + two tile accumulators and the camera ring per wave + queues
 #ifdef HPT_PROFILE
         lds_mega += waves_per_block * 3u * kProfSections * 8u;
 #endif

@@ -223,6 +223,9 @@ HD float portable_acos(float x) {
 
 // ------------------------------------------------- fixed-point radiance -----
 HD long long radiance_to_fixed(float v) {
+    // |v| < 64: v * 2^24 is exact in float (a power-of-two scale) and below 2^30, so the float rounding to an integer and
+    // the int32 conversion give the value of the double sequence below in five instructions instead of thirteen
+    if (fabsf(v) < 64.0f) return (long long)(int)__builtin_rintf(v * 16777216.0f);
     double x = (double)v;
     if (!(x == x)) return 0;
     if (x > 1048576.0) x = 1048576.0;
@@ -1471,14 +1474,18 @@ HD void bounce_tail(const DevScene& S, Path& p, float roulette_draw) {
 
 // Renderer.cpp:32-39 / CudaPathTrace.cu:39-59: jittered primary ray (one jitter
 // value for both axes), throughput 1, radiance 0.
-HD void generate_camera_path(const DevScene& S, uint32_t pixel, uint32_t sample, Path& p) {
+HD f3 camera_direction(const DevScene& S, uint32_t pixel, uint32_t sample) {
     const uint32_t i = pixel % (uint32_t)S.width, j = pixel / (uint32_t)S.width;
     const u4 r = philox4x32_10(kCameraDepth, 0u, S.seed, 0u, pixel, sample);
     const float bias = u01(r.x);
     const float x = (2 * ((float)i + bias) / (float)S.width - 1) * S.aspect * S.cam_scale;
     const float y = (1 - 2 * ((float)j + bias) / (float)S.height) * S.cam_scale;
+    return normalize(mk(-x, y, 1));
+}
+// the state of a path that leaves the camera along d
+HD void start_camera_path(const DevScene& S, uint32_t pixel, uint32_t sample, f3 d, Path& p) {
     p.o = mk(S.cam_x, S.cam_y, S.cam_z);
-    p.d = normalize(mk(-x, y, 1));
+    p.d = d;
     p.thr = mk(1.0f);
     p.rad = mk(0.0f);
     p.pdf = 0.0f;
@@ -1487,6 +1494,9 @@ HD void generate_camera_path(const DevScene& S, uint32_t pixel, uint32_t sample,
     p.diffused = false;
     p.pixel = pixel;
     p.sample = sample;
+}
+HD void generate_camera_path(const DevScene& S, uint32_t pixel, uint32_t sample, Path& p) {
+    start_camera_path(S, pixel, sample, camera_direction(S, pixel, sample), p);
 }
 
 // Scene::TracePath (common/Scene.hpp:122-272) for a path whose closest hit is
