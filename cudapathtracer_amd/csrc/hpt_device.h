@@ -208,17 +208,15 @@ HD float portable_asin_poly(float a, float z) {
     return p;
 }
 HD float portable_acos(float x) {
-    if (x > 0.5f) {
-        float z = 0.5f * (1.0f - x);
-        float s = sqrt_rn(z);
-        return 2.0f * portable_asin_poly(s, z);
-    }
-    if (x < -0.5f) {
-        float z = 0.5f * (1.0f + x);
-        float s = sqrt_rn(z);
-        return kPi - 2.0f * portable_asin_poly(s, z);
-    }
-    return 1.5707963267948966f - portable_asin_poly(x, x * x);
+    // Three ranges (x > 0.5, x < -0.5, between) that differ in the argument of one polynomial; the lanes of a wave
+    // fall into all three, so the ranges are selected, not branched on.  1 + x for x < -0.5 is 1 - |x|, the same float.
+    const bool outer = fabsf(x) > 0.5f;
+    const float z = outer ? 0.5f * (1.0f - fabsf(x)) : x * x;
+    const float a = outer ? sqrt_rn(z) : x;
+    const float p = portable_asin_poly(a, z);
+    const float inner = 1.5707963267948966f - p;
+    const float twice = 2.0f * p;
+    return outer ? (x > 0.5f ? twice : kPi - twice) : inner;
 }
 
 // ------------------------------------------------- fixed-point radiance -----
@@ -1235,14 +1233,14 @@ template <> struct Traversal<kSceneTiny64> : MarkTraversal<kSceneTiny64> {};
 // -------------------------------------------------------------- shading -----
 // common/MathUtils.hpp:124-222
 HD f3 local_to_world(f3 local_dir, f3 normal) {
-    f3 t;
-    if (fabsf(normal.x) > fabsf(normal.y)) {
-        const float inv_len = rcp_rn(sqrt_rn(normal.x * normal.x + normal.z * normal.z));
-        t = mk(normal.z * inv_len, 0.0f, -normal.x * inv_len);
-    } else {
-        const float inv_len = rcp_rn(sqrt_rn(normal.y * normal.y + normal.z * normal.z));
-        t = mk(0.0f, normal.z * inv_len, -normal.y * inv_len);
-    }
+    // The reference branches on |n.x| > |n.y| and builds the tangent from (n.x, n.z) or (n.y, n.z).  A wave holds
+    // lanes of both kinds, so the two sides are written as one: the same products, sum, square root and reciprocal
+    // on the selected component, then the zero goes where the branch would have put it.
+    const bool use_x = fabsf(normal.x) > fabsf(normal.y);
+    const float a = use_x ? normal.x : normal.y;
+    const float inv_len = rcp_rn(sqrt_rn(a * a + normal.z * normal.z));
+    const float tz = normal.z * inv_len, ta = -a * inv_len;
+    const f3 t = mk(use_x ? tz : 0.0f, use_x ? 0.0f : tz, ta);
     const f3 b = cross(t, normal);
     return local_dir.x * b + local_dir.y * t + local_dir.z * normal;
 }
