@@ -22,6 +22,8 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
             tot[r["Counter_Name"]] += float(r["Counter_Value"])
             disp[r["Counter_Name"]].add((f, r["Dispatch_Id"]))
 per = {k: tot[k] / len(disp[k]) for k in tot}
+if not per.get("SQ_INSTS_VALU") or "FETCH_SIZE" not in per:
+    sys.exit("no counters of a kernel matching %r under %s: nothing written" % (sub, root))
 lines = ["%-30s %18.0f  per-dispatch %16.0f  (%d dispatches)" % (k, tot[k], per[k], len(disp[k])) for k in sorted(tot)]
 # kernel durations from the trace pass
 for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True):
