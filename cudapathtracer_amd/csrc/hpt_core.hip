@@ -920,7 +920,7 @@ k_render_mega_sm(DevScene S, int max_depth, uint32_t s_begin_all, uint32_t s_cou
     // two accumulators (unit generations 0 / 1) of 64 pixels x RGB per wave
     unsigned long long* tile_acc = reinterpret_cast<unsigned long long*>(lds + S.lds_float4s) + wave * 384u;
     for (uint32_t i = lane; i < 384u; i += wave_lanes) tile_acc[i] = 0ull;
-    const TriQueue tq = make_tri_queue<kScene>(reinterpret_cast<uint32_t*>(lds + S.lds_float4s) + waves_per_block * (768u + kCamRingWords));  // (same layout as k_render_mega; the ring is not used here)
+    const TriQueue tq = make_tri_queue<kScene>(reinterpret_cast<uint32_t*>(lds + S.lds_float4s) + waves_per_block * 768u);
     stage_scene<kScene>(S, lds);
     const uint32_t W = (uint32_t)S.width, H = (uint32_t)S.height;
     const uint32_t tiles_x = (W + 7u) >> 3;
@@ -1533,7 +1533,13 @@ int render_launch(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sam
 
     if (mode == HPT_MODE_SINGLE_KERNEL) {
         const uint32_t waves_per_block = ((uint32_t)block + 63u) >> 6;
-        uint32_t lds_mega = lds + waves_per_block * (384u * 8u + kCamRingWords * 4u) + (lds_bytes(S, block) - lds);  // + two tile accumulators and the camera ring per wave + queues
+        // HPT_SCHEDULER_VARIANTS: bit mask of the traversal variants that run under the scheduler in this mode.
+        const char* sched_env = getenv("HPT_SCHEDULER");
+        const char* sched_mask = getenv("HPT_MEGA_SCHEDULER_VARIANTS");
+        const uint32_t mega_mask = sched_mask ? (uint32_t)strtoul(sched_mask, nullptr, 0) : kMegaSchedulerVariants;
+        const bool scheduler = has_scheduler(S.variant) && !(sched_env && atoi(sched_env) == 0) && ((mega_mask >> S.variant) & 1u);
+        // + two tile accumulators per wave + queues; the lock-step kernel also keeps its ring of camera directions there
+        uint32_t lds_mega = lds + waves_per_block * (384u * 8u + (scheduler ? 0u : kCamRingWords * 4u)) + (lds_bytes(S, block) - lds);
 #ifdef HPT_PROFILE
         lds_mega += waves_per_block * 3u * kProfSections * 8u;
 #endif
@@ -1553,11 +1559,6 @@ int render_launch(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sam
             return fail(HPT_ERR_INVALID_ARGUMENT, "a workgroup of %d lanes needs %u bytes of LDS for this scene (limit %u): use a smaller block", block, lds_mega, kMaxLdsPerBlock);
         int per_cu = 0;
         // HPT_SCHEDULER=0 (or, for the streamed mode, HPT_WF_SCHEDULER=0): the plain loops, for A/B runs.
-        // HPT_SCHEDULER_VARIANTS: bit mask of the traversal variants that run under the scheduler in this mode.
-        const char* sched_env = getenv("HPT_SCHEDULER");
-        const char* sched_mask = getenv("HPT_MEGA_SCHEDULER_VARIANTS");
-        const uint32_t mega_mask = sched_mask ? (uint32_t)strtoul(sched_mask, nullptr, 0) : kMegaSchedulerVariants;
-        const bool scheduler = has_scheduler(S.variant) && !(sched_env && atoi(sched_env) == 0) && ((mega_mask >> S.variant) & 1u);
 #define HPT_MEGA_KERNEL(kS, kG, kB) (scheduler ? reinterpret_cast<const void*>(&k_render_mega_sm<has_scheduler(kS) ? kS : kScenePair, kG, kB>) \
                                                : reinterpret_cast<const void*>(&k_render_mega<kS, kG, kB>))
         HPT_DISPATCH_RENDER(S.variant, ctx->extended, {
