@@ -351,3 +351,27 @@ def test_full_resolution_render_matches_oracle_bit_exact(hp, oracle, gpu_ctx, mo
     assert (st["closest_queries"], st["shadow_queries"]) == (ost["closest_queries"], ost["shadow_queries"])
     bad = np.flatnonzero((got != want).any(axis=1))
     assert bad.size == 0, "%d of %d pixels differ" % (bad.size, w * h)
+
+
+@pytest.mark.parametrize("spp_per_unit", ["1", "3", "40"])
+def test_unit_sizes_and_edge_tiles(hp, oracle, monkeypatch, spp_per_unit):
+    """The single-kernel mode's work units at other sizes than the default (HPT_SPP_PER_UNIT: pools of 64, 192 and
+    2 560 items for a full tile) on an image whose right and bottom tiles are partial (43 x 21: pools that are no
+    multiple of the wave size, batches of camera directions that end inside a pool): accumulators bit-exact."""
+    monkeypatch.setenv("HPT_SPP_PER_UNIT", spp_per_unit)
+    ctx = hp.Context(0)
+    try:
+        w, h, depth, spp = 43, 21, 6, 7
+        sc = hp.Scene.CreateBuiltinScene(hp.Scene.CornellBox, depth, w, h)
+        osc = oracle.cornell(w, h)
+        ctx.upload(sc)
+        want, ost = osc.render(RNG_PHILOX, TRIG_PORTABLE, depth, spp, fixed=True)
+        for block in (256, 100):
+            ctx.stats_reset()
+            ctx.accum_clear()
+            ctx.render(1, block, depth, 0, spp)
+            st = ctx.stats()
+            assert (st["closest_queries"], st["shadow_queries"], st["paths"]) == (ost["closest_queries"], ost["shadow_queries"], w * h * spp)
+            assert np.array_equal(ctx.accum_download(), want), (spp_per_unit, block)
+    finally:
+        ctx.close()
