@@ -123,6 +123,8 @@ def _declare(L, H):
     L.hpt_resolve_dev.argtypes = [vp, vp, u32, vp, vp]
     L.hpt_intersect_batch.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, vp, vp]
     L.hpt_intersect_batch_dev.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, vp, vp, i32, vp]
+    L.hpt_cast_rays.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, i32, vp]
+    L.hpt_cast_rays_dev.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, i32, vp, i32, vp]
     L.hpt_stats_get.argtypes = [vp, C.POINTER(hpt_stats)]
     L.hpt_stats_reset.argtypes = [vp]
     L.hpt_accum_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
@@ -150,6 +152,7 @@ def _declare(L, H):
     H.hpt_host_render_devices.argtypes = [vp, C.POINTER(C.c_int), i32, i32, i32, i32, i32, i32, vp, C.POINTER(hpt_stats)]
     H.hpt_host_save_ppm.argtypes = [C.c_char_p, vp, i32, i32]
     H.hpt_host_scene_intersect.argtypes = [vp, i32, C.c_size_t] + [vp] * 11
+    H.hpt_host_scene_cast_rays.argtypes = [vp, i32, C.c_uint32, C.c_uint32, C.c_size_t] + [vp] * 5
     H.hpt_host_material_eval.argtypes = [C.POINTER(hpt_material), C.c_size_t] + [vp] * 5
     H.hpt_host_material_sample.argtypes = [C.POINTER(hpt_material), C.c_size_t] + [vp] * 4
     H.hpt_host_rng_floats.argtypes = [i32, i32, i32, vp]
@@ -349,6 +352,22 @@ class Scene:
                                                                              "triangleArea", "material_type")]))
         return out
 
+    def castRay(self, o, d, pixel_key, sample_key, device=0, seed=0, integrator=0):
+        """Scene::castRay (common/Scene.hpp:274-285) of the C++ host class on a batch of eye rays, run on the GPU:
+        radiance float32[n, 3] after up to the scene's maxDepth bounces; ray i draws from the random stream of the
+        camera path (pixel_key[i], sample_key[i])."""
+        o = np.ascontiguousarray(o, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
+        pk = np.ascontiguousarray(pixel_key, np.uint32).reshape(-1)
+        sk = np.ascontiguousarray(sample_key, np.uint32).reshape(-1)
+        n = len(o)
+        if not (len(d) == len(pk) == len(sk) == n):
+            raise ValueError("castRay: one direction and one (pixel, sample) key per origin")
+        rgb = np.zeros((n, 3), np.float32)
+        _ckh(self._H.hpt_host_scene_cast_rays(self._h, int(device), int(seed), int(integrator), n, o.ctypes.data, d.ctypes.data,
+                                              pk.ctypes.data, sk.ctypes.data, rgb.ctypes.data))
+        return rgb
+
     def render_cpp(self, spp, max_depth, num_threads=256, mode=SingleKernel, device=0, iterative=False, devices=None):
         """Render through the C++ HipRenderer class: PrepareRender/Render/FinishRender, or
         (iterative) PrepareRender, PathTrace(scene, iter) spp times, FinishRender.
@@ -470,6 +489,25 @@ class Context:
         """Device pointers / torch tensors; asynchronous on ``stream``."""
         _ck(self._L.hpt_intersect_batch_dev(self._h, int(n), _ptr(o), _ptr(d), _ptr(shadow), _ptr(tmax), _ptr(prim),
                                             _ptr(t), int(block), _stream(stream)))
+
+    def cast_rays(self, o, d, pixel_key, sample_key, max_depth):
+        """Scene::castRay (common/Scene.hpp:274-285) for a batch of eye rays: host arrays in, radiance float32[n, 3]
+        out.  Ray r draws from the random stream of the camera path (pixel_key[r], sample_key[r])."""
+        o = np.ascontiguousarray(o, np.float32)
+        d = np.ascontiguousarray(d, np.float32)
+        pk = np.ascontiguousarray(pixel_key, np.uint32)
+        sk = np.ascontiguousarray(sample_key, np.uint32)
+        n = len(o)
+        if not (o.shape == d.shape == (n, 3) and pk.shape == sk.shape == (n,)):
+            raise ValueError("cast_rays: o and d are [n, 3], pixel_key and sample_key [n]")
+        rgb = np.zeros((n, 3), np.float32)
+        _ck(self._L.hpt_cast_rays(self._h, n, _ptr(o), _ptr(d), _ptr(pk), _ptr(sk), int(max_depth), _ptr(rgb)))
+        return rgb
+
+    def cast_rays_dev(self, n, o, d, pixel_key, sample_key, max_depth, rgb, block=256, stream=None):
+        """Device pointers / torch tensors; asynchronous on ``stream``."""
+        _ck(self._L.hpt_cast_rays_dev(self._h, int(n), _ptr(o), _ptr(d), _ptr(pixel_key), _ptr(sample_key), int(max_depth),
+                                      _ptr(rgb), int(block), _stream(stream)))
 
     def stats(self):
         st = hpt_stats()

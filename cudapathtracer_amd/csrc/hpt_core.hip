@@ -189,6 +189,47 @@ __global__ void k_intersect_batch(DevScene S, size_t n, const float* __restrict_
     }
 }
 
+// Scene::castRay (common/Scene.hpp:274-285) for caller-supplied eye rays, one lane per ray: the bounce loop of the render
+// kernels on a path that starts at (o, d) instead of at the camera and draws from the keyed stream of
+// (pixel_key, sample_key).  The radiance is written as floats, unnormalised.
+template <int kScene, bool kExt>
+__global__ void __launch_bounds__(256)
+k_cast_rays(DevScene S, size_t n, const float* __restrict__ o, const float* __restrict__ d, const uint32_t* __restrict__ pixel_key,
+            const uint32_t* __restrict__ sample_key, int max_depth, float* __restrict__ rgb, unsigned long long* __restrict__ stats) {
+    extern __shared__ float4 lds[];
+    stage_scene<kScene>(S, lds);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const TriQueue tq = make_tri_queue<kScene>(reinterpret_cast<uint32_t*>(lds + S.lds_float4s));
+#ifdef HPT_PROFILE
+    __shared__ unsigned long long prof_dummy[3 * kProfSections];
+    ProfAcc prof;
+    prof.w = prof_dummy;
+#endif
+    COUNT_DECL;
+    uint32_t n_closest = 0, n_shadow = 0, n_paths = 0;  // per lane; a lane runs at most 2^32 / max_depth rays (checked by the host)
+    for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) {
+        Path p;
+        start_camera_path(S, pixel_key[r], sample_key[r], mk(d[3 * r], d[3 * r + 1], d[3 * r + 2]), p);
+        p.o = mk(o[3 * r], o[3 * r + 1], o[3 * r + 2]);
+        bool alive = max_depth > 0;
+        while (alive) {
+            int tri;
+            double t;
+            ++n_closest;
+            trace<kScene, false>(S, lds, tq, p.o, p.d, 0.0, tri, t PROF_PASS COUNT_PASS);
+            alive = shade_bounce<kScene, kExt>(S, lds, tq, p, tri, t, n_shadow PROF_PASS COUNT_PASS) && p.depth < max_depth;
+        }
+        rgb[3 * r] = p.rad.x;
+        rgb[3 * r + 1] = p.rad.y;
+        rgb[3 * r + 2] = p.rad.z;
+        ++n_paths;
+    }
+    stat_add(stats + kStatClosest, n_closest);
+    stat_add(stats + kStatShadow, n_shadow);
+    stat_add(stats + kStatPaths, n_paths);
+    COUNT_FLUSH(stats);
+}
+
 __device__ __forceinline__ void accumulate_pixel(int64_t* accum, uint32_t pixel, f3 rad) {
     unsigned long long* a = reinterpret_cast<unsigned long long*>(accum) + 3ull * pixel;
     atomicAdd(a + 0, (unsigned long long)radiance_to_fixed(rad.x));
@@ -2306,6 +2347,54 @@ int hpt_intersect_batch(hpt_ctx* ctx, size_t n, const float* o, const float* d, 
 #undef ALLOC_OR_CLEAN
     cleanup();
     return rc;
+}
+
+int hpt_cast_rays_dev(hpt_ctx* ctx, size_t n, const float* o_dev, const float* d_dev, const uint32_t* pixel_key_dev,
+                      const uint32_t* sample_key_dev, int max_depth, float* rgb_dev, int block, void* stream) {
+    if (!ctx || !ctx->has_scene) return fail(HPT_ERR_NO_SCENE, "no scene uploaded");
+    if (n == 0) return HPT_OK;
+    if (!o_dev || !d_dev || !pixel_key_dev || !sample_key_dev || !rgb_dev) return fail(HPT_ERR_INVALID_ARGUMENT, "null ray/key/result pointer");
+    if (max_depth < 0 || max_depth > 16384) return fail(HPT_ERR_INVALID_ARGUMENT, "max_depth %d not in [0, 16384]", max_depth);
+    if (block < 1 || block > 256) return fail(HPT_ERR_INVALID_ARGUMENT, "block size %d not in [1, 256]", block);
+    if (int rc = set_device(ctx)) return rc;
+    const DevScene& S = ctx->S;
+    const uint32_t lds = lds_bytes(S, block);
+    const int grid = grid_for(ctx, n, block);
+    // the per-lane query counters are 32 bits wide
+    const uint64_t rays_per_lane = (n + (uint64_t)grid * (uint64_t)block - 1u) / ((uint64_t)grid * (uint64_t)block);
+    if (rays_per_lane * (uint64_t)(max_depth > 0 ? max_depth : 1) > 0xFFFFFFFFull)
+        return fail(HPT_ERR_TOO_LARGE, "%zu rays of up to %d bounces are too many for one call: split the batch", n, max_depth);
+    HPT_DISPATCH_RENDER(S.variant, ctx->extended, {
+        hipLaunchKernelGGL((k_cast_rays<kS, kG>), dim3(grid), dim3(block), lds, (hipStream_t)stream, S, n, o_dev, d_dev, pixel_key_dev, sample_key_dev,
+                           max_depth, rgb_dev, ctx->d_stats);
+    })
+    HIP_TRY(hipGetLastError());
+    return HPT_OK;
+}
+
+int hpt_cast_rays(hpt_ctx* ctx, size_t n, const float* o, const float* d, const uint32_t* pixel_key, const uint32_t* sample_key,
+                  int max_depth, float* rgb) {
+    if (!ctx || !ctx->has_scene) return fail(HPT_ERR_NO_SCENE, "no scene uploaded");
+    if (n == 0) return HPT_OK;
+    if (!o || !d || !pixel_key || !sample_key || !rgb) return fail(HPT_ERR_INVALID_ARGUMENT, "null ray/key/result pointer");
+    if (int rc = set_device(ctx)) return rc;
+    // one staging block: origins, directions, radiance (3 floats each), the two keys
+    float* stage = nullptr;
+    if (int rc = device_alloc((void**)&stage, n * 44, "eye ray staging")) return rc;
+    float *d_o = stage, *d_d = stage + 3 * n, *d_rgb = stage + 6 * n;
+    uint32_t *d_pk = reinterpret_cast<uint32_t*>(stage + 9 * n), *d_sk = d_pk + n;
+    int rc = HPT_OK;
+    hipError_t e = hipMemcpy(d_o, o, n * 12, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_d, d, n * 12, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_pk, pixel_key, n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_sk, sample_key, n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) rc = hpt_cast_rays_dev(ctx, n, d_o, d_d, d_pk, d_sk, max_depth, d_rgb, 256, nullptr);
+    if (e == hipSuccess && rc == HPT_OK) e = hipDeviceSynchronize();
+    if (e == hipSuccess && rc == HPT_OK) e = hipMemcpy(rgb, d_rgb, n * 12, hipMemcpyDeviceToHost);
+    (void)hipFree(stage);
+    if (rc != HPT_OK) return rc;
+    if (e != hipSuccess) return fail(HPT_ERR_HIP, "hpt_cast_rays: %s", hipGetErrorString(e));
+    return HPT_OK;
 }
 
 int hpt_stats_get(hpt_ctx* ctx, hpt_stats* out) {

@@ -291,22 +291,52 @@ const FlatScene& Scene::flat() const {
     return *flat_;
 }
 
-std::vector<Intersection> Scene::intersect(const std::vector<Ray>& rays) const {
+hpt_ctx* Scene::queryContext() const {
     const FlatScene& f = flat();
     if (!query_ctx_) {
         hpt_ctx* ctx = nullptr;
-        if (hpt_context_create(query_device, &ctx) != HPT_OK) throw std::runtime_error(std::string("Scene::intersect: ") + hpt_last_error());
+        if (hpt_context_create(query_device, &ctx) != HPT_OK) throw std::runtime_error(std::string("Scene: ") + hpt_last_error());
         query_ctx_ = std::shared_ptr<hpt_ctx>(ctx, [](hpt_ctx* c) { hpt_context_destroy(c); });
         const hpt_scene_desc d = describe();
         if (hpt_set_bvh_build(ctx, f.gpu_build ? HPT_BVH_BUILD_GPU : HPT_BVH_BUILD_HOST) != HPT_OK || hpt_scene_upload(ctx, &d) != HPT_OK) {
             query_ctx_.reset();
-            throw std::runtime_error(std::string("Scene::intersect: ") + hpt_last_error());
+            throw std::runtime_error(std::string("Scene: ") + hpt_last_error());
         }
         int32_t prims = 0;
         for (int32_t p : f.prim_of_tri) prims = std::max(prims, p + 1);
         tri_of_prim_.assign((size_t)prims, -1);
         for (size_t t = 0; t < f.prim_of_tri.size(); ++t) tri_of_prim_[(size_t)f.prim_of_tri[t]] = (int32_t)t;
     }
+    return query_ctx_.get();
+}
+
+std::vector<Vec3> Scene::castRay(const std::vector<PathKey>& keys, const std::vector<Ray>& eyeRays) const {
+    if (keys.size() != eyeRays.size()) throw std::invalid_argument("Scene::castRay: one key per eye ray");
+    hpt_ctx* ctx = queryContext();
+    const size_t n = eyeRays.size();
+    std::vector<Vec3> out(n);
+    if (n == 0) return out;
+    std::vector<float> o(3 * n), d(3 * n), rgb(3 * n);
+    std::vector<uint32_t> pk(n), sk(n);
+    for (size_t i = 0; i < n; ++i) {
+        const Ray& r = eyeRays[i];
+        o[3 * i] = r.origin.x; o[3 * i + 1] = r.origin.y; o[3 * i + 2] = r.origin.z;
+        d[3 * i] = r.direction.x; d[3 * i + 1] = r.direction.y; d[3 * i + 2] = r.direction.z;
+        pk[i] = keys[i].pixel;
+        sk[i] = keys[i].sample;
+    }
+    if (hpt_set_seed(ctx, query_seed) != HPT_OK || hpt_set_integrator(ctx, query_integrator) != HPT_OK ||
+        hpt_cast_rays(ctx, n, o.data(), d.data(), pk.data(), sk.data(), maxDepth, rgb.data()) != HPT_OK)
+        throw std::runtime_error(std::string("Scene::castRay: ") + hpt_last_error());
+    for (size_t i = 0; i < n; ++i) out[i] = Vec3(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]);
+    return out;
+}
+
+Vec3 Scene::castRay(PathKey key, const Ray& eyeRay) const { return castRay(std::vector<PathKey>{key}, std::vector<Ray>{eyeRay})[0]; }
+
+std::vector<Intersection> Scene::intersect(const std::vector<Ray>& rays) const {
+    const FlatScene& f = flat();
+    hpt_ctx* query = queryContext();
     const size_t n = rays.size();
     std::vector<Intersection> out(n);
     if (n == 0) return out;
@@ -321,7 +351,7 @@ std::vector<Intersection> Scene::intersect(const std::vector<Ray>& rays) const {
         shadow[i] = r.shadowTest ? 1 : 0;
         tmax[i] = r.shadowDistance;
     }
-    if (hpt_intersect_batch(query_ctx_.get(), n, o.data(), d.data(), shadow.data(), tmax.data(), prim.data(), t.data()) != HPT_OK)
+    if (hpt_intersect_batch(query, n, o.data(), d.data(), shadow.data(), tmax.data(), prim.data(), t.data()) != HPT_OK)
         throw std::runtime_error(std::string("Scene::intersect: ") + hpt_last_error());
     for (size_t i = 0; i < n; ++i) {
         if (prim[i] < 0) continue;

@@ -1,8 +1,8 @@
 // Scene: the host-side scene description with the public members and methods
 // of the reference's Scene that callers use (common/Scene.hpp:20-93):
 // resolution, camera, maxDepth, Add(), buildBVH(), CreateBuiltinScene(), the
-// light totals, intersect().  TracePath/castRay are not host functions here: the
-// bounce loop runs on the device, and so do the queries of intersect(); buildBVH()
+// light totals, intersect(), castRay().  TracePath is not a host function here: the
+// bounce loop runs on the device, and so do the queries of intersect() and castRay(); buildBVH()
 // additionally emits the flattened records that hpt_scene_upload() consumes.
 #pragma once
 #include <memory>
@@ -116,6 +116,18 @@ public:
     std::vector<Intersection> intersect(const std::vector<Ray>& rays) const;
     int query_device = 0;
 
+    // Scene::castRay (common/Scene.hpp:274-285) for host callers: the radiance along an eye ray after up to
+    // maxDepth bounces of intersect + TracePath, computed on the GPU (hpt_cast_rays, same context as intersect()).
+    // The reference hands castRay an RNG object; the device draws from a keyed stream instead, so the caller names the
+    // stream: that of the camera path (pixel, sample) under seed `query_seed`.  The eye ray of that path returns that
+    // path's radiance; rays that share a key are correlated.  `query_integrator`: HPT_INTEGRATOR_* flags.
+    struct PathKey {
+        uint32_t pixel, sample;
+    };
+    Vec3 castRay(PathKey key, const Ray& eyeRay) const;
+    std::vector<Vec3> castRay(const std::vector<PathKey>& keys, const std::vector<Ray>& eyeRays) const;
+    uint32_t query_seed = 0, query_integrator = 0;
+
     // valid after buildBVH(); pointers inside stay valid while the scene lives
     const FlatScene& flat() const;
     hpt_scene_desc describe() const;
@@ -128,6 +140,7 @@ private:
     std::shared_ptr<FlatScene> flat_;
     void buildForGpu();
     void fillMaterialsAndLights(FlatScene& fs) const;
-    mutable std::shared_ptr<hpt_ctx> query_ctx_;   // intersect(): created and uploaded on first use
+    hpt_ctx* queryContext() const;
+    mutable std::shared_ptr<hpt_ctx> query_ctx_;   // intersect() / castRay(): created and uploaded on first use
     mutable std::vector<int32_t> tri_of_prim_;     // global primitive id -> triangle record
 };

@@ -316,6 +316,26 @@ int hpt_host_scene_intersect(const hpt_host_scene* s, int device, size_t n, cons
     })
 }
 
+int hpt_host_scene_cast_rays(const hpt_host_scene* s, int device, uint32_t seed, uint32_t integrator, size_t n, const float* o, const float* d,
+                             const uint32_t* pixel_key, const uint32_t* sample_key, float* rgb) {
+    if (!s || (n && (!o || !d || !pixel_key || !sample_key || !rgb))) return fail("null argument");
+    GUARD({
+        Scene& scene = const_cast<Scene&>(s->scene);
+        scene.query_device = device;
+        scene.query_seed = seed;
+        scene.query_integrator = integrator;
+        std::vector<Ray> rays(n);
+        std::vector<Scene::PathKey> keys(n);
+        for (size_t i = 0; i < n; ++i) {
+            rays[i] = Ray(Vec3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), Vec3(d[3 * i], d[3 * i + 1], d[3 * i + 2]));
+            keys[i].pixel = pixel_key[i];
+            keys[i].sample = sample_key[i];
+        }
+        const std::vector<Vec3> radiance = s->scene.castRay(keys, rays);
+        for (size_t i = 0; i < n; ++i) { rgb[3 * i] = radiance[i].x; rgb[3 * i + 1] = radiance[i].y; rgb[3 * i + 2] = radiance[i].z; }
+    })
+}
+
 int hpt_host_material_eval(const hpt_material* material, size_t n, const float* ray_source_dir, const float* ray_out_dir,
                            const float* normal, float* bsdf, float* pdf) {
     if (!material || (n && (!ray_source_dir || !ray_out_dir || !normal))) return fail("null argument");

@@ -259,6 +259,24 @@ int hpt_intersect_batch(hpt_ctx* ctx, size_t n, const float* o, const float* d, 
 int hpt_intersect_batch_dev(hpt_ctx* ctx, size_t n, const float* o_dev, const float* d_dev, const uint8_t* shadow_dev,
                             const double* tmax_dev, int32_t* prim_dev, double* t_dev, int block, void* stream);
 
+/* Radiance along caller-supplied eye rays; the device counterpart of Scene::castRay
+ * (common/Scene.hpp:274-285: up to max_depth bounces of Scene::intersect + Scene::TracePath) for a batch.
+ *   o, d:        float[3*n] origins / directions of the eye rays (d as Ray::direction: normalised by the caller)
+ *   pixel_key,
+ *   sample_key:  uint32[n]  the random stream ray r draws from: that of the camera path of pixel pixel_key[r],
+ *                sample sample_key[r] (with the context's seed).  Draws are addressed by (stream, bounce, slot), so a ray
+ *                equal to that path's camera ray returns exactly that path's radiance, and two rays with one key
+ *                are correlated: give every ray of a batch its own key.
+ *   rgb:         float[3*n] castRay's return value: radiance, not normalised, not clamped (NaN/inf pass through)
+ * The context's integrator flags, seed and traversal apply as in hpt_render; the accumulators are not touched;
+ * closest/shadow queries and paths are added to the counters of hpt_stats_get.
+ * Host-pointer form (copies in and out, synchronous) and device-pointer form (asynchronous on `stream`,
+ * block in [1, 256]). */
+int hpt_cast_rays(hpt_ctx* ctx, size_t n, const float* o, const float* d, const uint32_t* pixel_key,
+                  const uint32_t* sample_key, int max_depth, float* rgb);
+int hpt_cast_rays_dev(hpt_ctx* ctx, size_t n, const float* o_dev, const float* d_dev, const uint32_t* pixel_key_dev,
+                      const uint32_t* sample_key_dev, int max_depth, float* rgb_dev, int block, void* stream);
+
 /* Ray counters, kernel time and launch count accumulated since the last
  * hpt_stats_reset.  Synchronises the device. */
 int hpt_stats_get(hpt_ctx* ctx, hpt_stats* out);

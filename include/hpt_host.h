@@ -91,6 +91,12 @@ int hpt_host_scene_intersect(const hpt_host_scene* s, int device, size_t n, cons
                              const double* tmax, uint8_t* happened, int32_t* prim, double* distance, float* coords, float* normal,
                              float* triangle_area, int32_t* material_type);
 
+/* Scene::castRay (common/Scene.hpp:274-285) on a batch of eye rays, run on GPU `device` (hpt_cast_rays on the context the
+ * scene keeps): rgb[3*n] = radiance after up to the scene's maxDepth bounces.  Ray i draws from the keyed random stream of
+ * the camera path (pixel_key[i], sample_key[i]) under `seed`; integrator: HPT_INTEGRATOR_* flags (include/hpt.h). */
+int hpt_host_scene_cast_rays(const hpt_host_scene* s, int device, uint32_t seed, uint32_t integrator, size_t n, const float* o,
+                             const float* d, const uint32_t* pixel_key, const uint32_t* sample_key, float* rgb);
+
 /* Material::bsdf / Material::pdf (common/Material.hpp:257-384) and Material::sample (:186-219, with the three uniform draws
  * given per sample in u3, in the order Material::sample(RNG&) draws them) of the host Material class, n directions each; libm transcendentals like the
  * reference's CPU build.  The renderer does not use them (materials are evaluated on the device). */

@@ -1290,6 +1290,30 @@ void orc_cast_paths(const orc_scene* s, int rng_mode, int trig_mode, uint32_t se
     }
 }
 
+// Scene::castRay (common/Scene.hpp:274-285) for caller-supplied eye rays.  The random stream of ray q is
+// Rng(rng_mode, seed, sample_k[q], pixel_m[q]) from its beginning: with the keyed Philox stream that is the stream of
+// the camera path of that pixel and sample (draws are addressed by bounce and slot, the camera's draw has a bounce
+// number of its own), so a ray that equals that path's camera ray returns that path's radiance.
+void orc_cast_rays(const orc_scene* s, int rng_mode, int trig_mode, uint32_t seed, int max_depth, int64_t n, const float* o,
+                   const float* d, const int32_t* sample_k, const int32_t* pixel_m, float* rgb_out, int threads, orc_stats* stats) {
+    const Scene& sc = s->sc;
+    Trig tg;
+    tg.portable = trig_mode == ORC_TRIG_PORTABLE;
+    if (threads <= 0) threads = omp_get_max_threads();
+    if (stats) std::memset(stats, 0, sizeof *stats);
+#pragma omp parallel num_threads(threads)
+    {
+        Tally tl;
+#pragma omp for schedule(dynamic, 256)
+        for (int64_t q = 0; q < n; ++q) {
+            Rng rng(rng_mode, seed, sample_k[q], pixel_m[q]);
+            V3 L = castRay(sc, tg, rng, Ray(mk(o[3 * q], o[3 * q + 1], o[3 * q + 2]), mk(d[3 * q], d[3 * q + 1], d[3 * q + 2])), max_depth, tl);
+            rgb_out[3 * q] = L.x; rgb_out[3 * q + 1] = L.y; rgb_out[3 * q + 2] = L.z;
+        }
+        mergeStats(stats, tl);
+    }
+}
+
 void orc_rng_floats(int rng_mode, uint32_t seed, int iter, int index, int count, float* out) {
     Rng rng(rng_mode, seed, iter, index);
     for (int i = 0; i < count; ++i) out[i] = rng.draw(0, (uint32_t)i);

@@ -88,6 +88,11 @@ void orc_render(const orc_scene*, int rng_mode, int trig_mode, uint32_t seed, in
 void orc_cast_paths(const orc_scene*, int rng_mode, int trig_mode, uint32_t seed, int max_depth, int64_t n,
                     const int32_t* sample_k, const int32_t* pixel_m, float* rgb_out, int threads, orc_stats* stats);
 
+/* Scene::castRay (common/Scene.hpp:274-285) for caller-supplied eye rays (o, d: 3 floats each); ray q draws from the
+ * stream of (sample_k[q], pixel_m[q]) */
+void orc_cast_rays(const orc_scene*, int rng_mode, int trig_mode, uint32_t seed, int max_depth, int64_t n, const float* o,
+                   const float* d, const int32_t* sample_k, const int32_t* pixel_m, float* rgb_out, int threads, orc_stats* stats);
+
 /* ---- unit-level entry points (shading vectors) ---- */
 void orc_rng_floats(int rng_mode, uint32_t seed, int iter, int index, int count, float* out);
 void orc_material_eval(const orc_material*, int64_t n, const float* wi, const float* wo, const float* nrm,

@@ -76,6 +76,8 @@ class Oracle:
                                  C.c_void_p, C.c_void_p, C.POINTER(Stats)]
         L.orc_cast_paths.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_int, C.POINTER(Stats)]
+        L.orc_cast_rays.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int64] + [C.c_void_p] * 5 + [
+            C.c_int, C.POINTER(Stats)]
         L.orc_rng_floats.argtypes = [C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.orc_material_eval.argtypes = [C.POINTER(Material), C.c_int64] + [C.c_void_p] * 5
         L.orc_material_sample.argtypes = [C.POINTER(Material), C.c_int, C.c_int64] + [C.c_void_p] * 4
@@ -253,6 +255,15 @@ class OracleScene:
         out = np.zeros((len(k), 3), np.float32)
         st = Stats()
         self.lib.orc_cast_paths(self.h, rng, trig, seed, max_depth, len(k), _p(k), _p(m), _p(out), threads, C.byref(st))
+        return out, st.as_dict()
+
+    def cast_rays(self, rng, trig, max_depth, o, d, samples, pixels, seed=0, threads=0):
+        o, d = _f32(o), _f32(d)
+        k = np.ascontiguousarray(samples, np.int32)
+        m = np.ascontiguousarray(pixels, np.int32)
+        out = np.zeros((len(k), 3), np.float32)
+        st = Stats()
+        self.lib.orc_cast_rays(self.h, rng, trig, seed, max_depth, len(k), _p(o), _p(d), _p(k), _p(m), _p(out), threads, C.byref(st))
         return out, st.as_dict()
 
     def sample_light(self, u4):

@@ -4,13 +4,14 @@ import numpy as np
 
 
 def primary_rays(width, height, cam_pos, scale, bias=0.5):
-    """Pixel-centre camera rays with the reference's camera maths in float32
-    (common/Renderer.cpp:37-39)."""
+    """Camera rays with the reference's camera maths in float32 (common/Renderer.cpp:37-39); bias: the jitter of
+    Renderer.cpp:32, one number (0.5 = pixel centres) or an array [height, width] of per-pixel draws."""
     f = np.float32
     j, i = np.meshgrid(np.arange(height, dtype=np.float32), np.arange(width, dtype=np.float32), indexing="ij")
     aspect = f(width) / f(height)
-    x = (f(2) * (i + f(bias)) / f(width) - f(1)) * aspect * f(scale)
-    y = (f(1) - f(2) * (j + f(bias)) / f(height)) * f(scale)
+    bias = np.asarray(bias, np.float32)
+    x = (f(2) * (i + bias) / f(width) - f(1)) * aspect * f(scale)
+    y = (f(1) - f(2) * (j + bias) / f(height)) * f(scale)
     d = np.stack([-x, y, np.ones_like(x)], -1).reshape(-1, 3).astype(np.float32)
     inv = f(1) / np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2], dtype=np.float32)
     d = (d * inv[:, None]).astype(np.float32)

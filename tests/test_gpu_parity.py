@@ -375,3 +375,44 @@ def test_unit_sizes_and_edge_tiles(hp, oracle, monkeypatch, spp_per_unit):
             assert np.array_equal(ctx.accum_download(), want), (spp_per_unit, block)
     finally:
         ctx.close()
+
+
+def test_cast_rays_equals_oracle_bit_exact(cornell, hp):
+    """Scene::castRay on caller-supplied eye rays (hpt_cast_rays): radiance floats and query counters equal the
+    oracle's for random rays inside the box with random stream keys, and for the camera rays of two samples, which
+    also equal the paths of the render (oracle cast_paths)."""
+    sc, osc, ctx = cornell
+    depth = 8
+    n = 1 << 15
+    o, d = random_rays(n, seed=21)
+    rs = np.random.RandomState(22)
+    pk, sk = rs.randint(0, 1 << 20, n), rs.randint(0, 4096, n)
+    want, ost = osc.cast_rays(RNG_PHILOX, TRIG_PORTABLE, depth, o, d, sk, pk)
+    ctx.stats_reset()
+    got = ctx.cast_rays(o, d, pk, sk, depth)
+    st = ctx.stats()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert (st["closest_queries"], st["shadow_queries"], st["paths"]) == (ost["closest_queries"], ost["shadow_queries"], n)
+    assert want.max() > 0 and (want.sum(1) == 0).mean() < 0.9
+
+    w = h = 512
+    pix = np.arange(w * h)[:: 37]
+    for k in (0, 5):
+        bias = np.zeros(w * h, np.float32)
+        bias[pix] = [osc.lib.orc_philox_uniform(int(m), k, 0xFFFFFFFF, 0, 0) for m in pix]
+        o, d = primary_rays(w, h, (278, 273, -800), osc.info()["cam_scale"], bias.reshape(h, w))
+        want, _ = osc.cast_paths(RNG_PHILOX, TRIG_PORTABLE, depth, np.full(len(pix), k), pix)
+        got = ctx.cast_rays(o[pix], d[pix], pix, np.full(len(pix), k), depth)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+    # depth 0, an empty batch, bad arguments
+    assert not ctx.cast_rays(o[:100], d[:100], np.arange(100), np.zeros(100), 0).any()
+    assert ctx.cast_rays(np.zeros((0, 3)), np.zeros((0, 3)), [], [], depth).shape == (0, 3)
+    with pytest.raises(hp.HptError):
+        ctx.cast_rays(o[:4], d[:4], np.arange(4), np.zeros(4), -1)
+    with pytest.raises(hp.HptError):
+        ctx.cast_rays_dev(4, 0, 0, 0, 0, depth, 0)
+    with pytest.raises(hp.HptError):
+        import torch
+        t = torch.zeros(64, device="cuda")
+        ctx.cast_rays_dev(4, t, t, t, t, depth, t, block=512)

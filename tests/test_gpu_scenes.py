@@ -544,6 +544,32 @@ def test_host_scene_intersect_equals_oracle(hp, oracle):
     assert len(sc.intersect(np.zeros((0, 3)), np.zeros((0, 3)))["prim"]) == 0
 
 
+def test_host_scene_cast_ray_equals_oracle(hp, oracle):
+    """Scene::castRay of the C++ host class (common/Scene.hpp:274-285), which runs the paths on the GPU: radiance
+    bit-exact against the oracle for random eye rays and keys, with another seed and Russian roulette too; a
+    single-ray call; an empty batch; mismatched lengths."""
+    depth = 7
+    sc = hp.Scene.CreateBuiltinScene(hp.Scene.CornellBox, depth)
+    osc = oracle.cornell()
+    n = 20000
+    o, d = random_rays(n, seed=61)
+    rs = np.random.RandomState(62)
+    pk, sk = rs.randint(0, 1 << 18, n), rs.randint(0, 256, n)
+    want, _ = osc.cast_rays(RNG_PHILOX, TRIG_PORTABLE, depth, o, d, sk, pk)
+    got = sc.castRay(o, d, pk, sk)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)) and want.max() > 0
+    one = sc.castRay(o[5:6], d[5:6], pk[5:6], sk[5:6])
+    assert np.array_equal(one.view(np.uint32), want[5:6].view(np.uint32))
+    osc.set_integrator(True, False)
+    want2, _ = osc.cast_rays(RNG_PHILOX, TRIG_PORTABLE, depth, o, d, sk, pk, seed=9)
+    got2 = sc.castRay(o, d, pk, sk, seed=9, integrator=hp.api.INTEGRATOR_RUSSIAN_ROULETTE)
+    assert np.array_equal(got2.view(np.uint32), want2.view(np.uint32)) and not np.array_equal(want2, want)
+    assert np.array_equal(sc.castRay(o, d, pk, sk).view(np.uint32), want.view(np.uint32))   # the options do not stick
+    assert sc.castRay(np.zeros((0, 3)), np.zeros((0, 3)), [], []).shape == (0, 3)
+    with pytest.raises(ValueError):
+        sc.castRay(o[:4], d[:4], pk[:3], sk[:4])
+
+
 def _hits_equal_up_to_ties(got, want, what):
     """Closest hits of a tree other than the reference's over the same leaf boxes: every distance is the
     reference's bit for bit; the primitive may differ only where two are hit at that very distance."""
@@ -741,3 +767,39 @@ def test_bunny_full_resolution_render_matches_oracle_bit_exact(hp, oracle, gpu_c
     assert (st["closest_queries"], st["shadow_queries"]) == (ost["closest_queries"], ost["shadow_queries"])
     bad = np.flatnonzero((got != want).any(axis=1))
     assert bad.size == 0, "%d of %d pixels differ" % (bad.size, w * h)
+
+
+@pytest.mark.parametrize("name", ["spheres", "spheres_bunny", "bunny_metal_rr_reg", "heightfield4", "heightfield128"])
+def test_cast_rays_on_other_scenes(hp, oracle, gpu_ctx, name):
+    """hpt_cast_rays (Scene::castRay for caller-supplied eye rays) through the other kernels: glass and spheres with
+    the two-child records in LDS and through L1/L2, Russian roulette + regularisation on a metal bunny, the 64-bit
+    marking variant, a height field; radiance floats and counters bit-exact against the oracle."""
+    from cudapathtracer_amd import scenes
+    w, h, depth, n = 32, 32, 9, 1 << 14
+    rr = reg = False
+    if name.startswith("spheres"):
+        sc, osc = _sphere_scene(hp, oracle, w, h, depth, big=name.endswith("bunny"))
+    else:
+        if name.startswith("bunny"):
+            parts = scenes.cornell_shell_triangles() + [("bunny", scenes.bunny_triangles(), scenes.METAL)]
+            rr = reg = True
+        else:
+            parts = scenes.heightfield_in_cornell_parts(int(name[11:]))
+        sc = scenes._assemble(parts, w, h, depth)
+        osc = _oracle_scene(oracle, parts, w, h)
+    osc.set_integrator(rr, reg)
+    gpu_ctx.upload(sc)
+    gpu_ctx.set_integrator(rr, reg)
+    try:
+        o, d = random_rays(n, 91)
+        rs = np.random.RandomState(92)
+        pk, sk = rs.randint(0, 1 << 24, n), rs.randint(0, 1 << 16, n)
+        want, ost = osc.cast_rays(RNG_PHILOX, TRIG_PORTABLE, depth, o, d, sk, pk)
+        gpu_ctx.stats_reset()
+        got = gpu_ctx.cast_rays(o, d, pk, sk, depth)
+        st = gpu_ctx.stats()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        assert (st["closest_queries"], st["shadow_queries"], st["paths"]) == (ost["closest_queries"], ost["shadow_queries"], n)
+        assert want.max() > 0
+    finally:
+        gpu_ctx.set_integrator(False, False)

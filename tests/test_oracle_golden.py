@@ -395,3 +395,24 @@ def test_cpu_path_tracer_cli_writes_the_reference_picture(oracle, tmp_path):
     assert np.array_equal(got, want)
     r = subprocess.run([exe, "0", "5", "3"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=60)
     assert r.returncode == 2 and "usage" in r.stderr
+
+
+def test_cast_rays_equals_cast_paths_on_the_camera_rays(oracle):
+    """Scene::castRay on caller-supplied eye rays: handed the camera ray of (pixel, sample) and that path's stream it
+    returns that path's radiance bit for bit (keyed Philox stream); arbitrary rays and depth 0 run too."""
+    w, h, depth = 24, 20, 6
+    sc = oracle.cornell(w, h)
+    scale = sc.info()["cam_scale"]
+    for k in (0, 3):
+        bias = np.array([oracle.philox_uniform(m, k, 0xFFFFFFFF, 0) for m in range(w * h)], np.float32).reshape(h, w)
+        o, d = primary_rays(w, h, CAM, scale, bias)
+        pix = np.arange(w * h)
+        want, st_want = sc.cast_paths(RNG_PHILOX, TRIG_PORTABLE, depth, np.full(w * h, k), pix)
+        got, st = sc.cast_rays(RNG_PHILOX, TRIG_PORTABLE, depth, o, d, np.full(w * h, k), pix)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        assert st == st_want
+    o, d = random_rays(500, 5)
+    a, st = sc.cast_rays(RNG_PHILOX, TRIG_PORTABLE, depth, o, d, np.arange(500) % 7, np.arange(500))
+    assert st["paths"] == 500 and st["closest_queries"] >= 500 and np.isfinite(a).all() and (a >= 0).all() and a.max() > 0
+    z, st = sc.cast_rays(RNG_PHILOX, TRIG_PORTABLE, 0, o, d, np.zeros(500), np.arange(500))
+    assert not z.any() and st["closest_queries"] == 0
