@@ -1314,6 +1314,49 @@ void orc_cast_rays(const orc_scene* s, int rng_mode, int trig_mode, uint32_t see
     }
 }
 
+// The rays that camera paths trace at bounce `bounce` (0 = the camera rays), as Scene::castRay (common/Scene.hpp:274-285)
+// hands them to Scene::intersect: an incoherent ray batch with the directions and origins a render really produces.
+// alive_out[q] = 0 when path q ended before that bounce (its o/d are left untouched).
+void orc_capture_bounce_rays(const orc_scene* s, int rng_mode, int trig_mode, uint32_t seed, int bounce, int64_t n,
+                             const int32_t* sample_k, const int32_t* pixel_m, float* o_out, float* d_out, uint8_t* alive_out, int threads) {
+    const Scene& sc = s->sc;
+    Trig tg;
+    tg.portable = trig_mode == ORC_TRIG_PORTABLE;
+    const float scale = cameraScale(sc.fov);
+    if (threads <= 0) threads = omp_get_max_threads();
+#pragma omp parallel num_threads(threads)
+    {
+        Tally tl;
+#pragma omp for schedule(dynamic, 256)
+        for (int64_t q = 0; q < n; ++q) {
+            // pixelSample (Renderer.cpp:32-40), then castRay's loop cut off at `bounce`
+            const int k = sample_k[q], m = pixel_m[q];
+            uint32_t i = (uint32_t)m % (uint32_t)sc.width, j = (uint32_t)m / (uint32_t)sc.width;
+            float imageAspectRatio = sc.width / (float)sc.height;
+            Rng rng(rng_mode, seed, k, m);
+            float bias = rng.draw(kCameraDepth, 0);
+            float x = (2 * (i + bias) / (float)sc.width - 1) * imageAspectRatio * scale;
+            float y = (1 - 2 * (j + bias) / (float)sc.height) * scale;
+            PathSegment path;
+            path.rng = rng;
+            path.ray = Ray(sc.camPos, normalize(mk(-x, y, 1)));
+            path.remainingBounces = bounce + 1;
+            for (int depth = 0; depth < bounce; depth++) {
+                if (path.remainingBounces <= 0) break;
+                Intersection intersec = sceneIntersect(sc, path.ray, tl);
+                path.remainingBounces -= 1;
+                TracePath(sc, tg, path, intersec, tl);
+            }
+            const bool alive = path.remainingBounces > 0;
+            alive_out[q] = alive ? 1 : 0;
+            if (alive) {
+                o_out[3 * q] = path.ray.origin.x; o_out[3 * q + 1] = path.ray.origin.y; o_out[3 * q + 2] = path.ray.origin.z;
+                d_out[3 * q] = path.ray.direction.x; d_out[3 * q + 1] = path.ray.direction.y; d_out[3 * q + 2] = path.ray.direction.z;
+            }
+        }
+    }
+}
+
 void orc_rng_floats(int rng_mode, uint32_t seed, int iter, int index, int count, float* out) {
     Rng rng(rng_mode, seed, iter, index);
     for (int i = 0; i < count; ++i) out[i] = rng.draw(0, (uint32_t)i);

@@ -93,6 +93,11 @@ void orc_cast_paths(const orc_scene*, int rng_mode, int trig_mode, uint32_t seed
 void orc_cast_rays(const orc_scene*, int rng_mode, int trig_mode, uint32_t seed, int max_depth, int64_t n, const float* o,
                    const float* d, const int32_t* sample_k, const int32_t* pixel_m, float* rgb_out, int threads, orc_stats* stats);
 
+/* the rays camera paths (sample_k[q], pixel_m[q]) trace at bounce `bounce` (0 = camera rays): an incoherent batch as a
+ * render produces it; alive_out[q] = 0 when the path ended earlier (o/d untouched) */
+void orc_capture_bounce_rays(const orc_scene*, int rng_mode, int trig_mode, uint32_t seed, int bounce, int64_t n,
+                             const int32_t* sample_k, const int32_t* pixel_m, float* o_out, float* d_out, uint8_t* alive_out, int threads);
+
 /* ---- unit-level entry points (shading vectors) ---- */
 void orc_rng_floats(int rng_mode, uint32_t seed, int iter, int index, int count, float* out);
 void orc_material_eval(const orc_material*, int64_t n, const float* wi, const float* wo, const float* nrm,

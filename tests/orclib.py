@@ -78,6 +78,7 @@ class Oracle:
                                      C.c_void_p, C.c_int, C.POINTER(Stats)]
         L.orc_cast_rays.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int64] + [C.c_void_p] * 5 + [
             C.c_int, C.POINTER(Stats)]
+        L.orc_capture_bounce_rays.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int64] + [C.c_void_p] * 5 + [C.c_int]
         L.orc_rng_floats.argtypes = [C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.orc_material_eval.argtypes = [C.POINTER(Material), C.c_int64] + [C.c_void_p] * 5
         L.orc_material_sample.argtypes = [C.POINTER(Material), C.c_int, C.c_int64] + [C.c_void_p] * 4
@@ -265,6 +266,17 @@ class OracleScene:
         st = Stats()
         self.lib.orc_cast_rays(self.h, rng, trig, seed, max_depth, len(k), _p(o), _p(d), _p(k), _p(m), _p(out), threads, C.byref(st))
         return out, st.as_dict()
+
+    def bounce_rays(self, rng, trig, bounce, samples, pixels, seed=0, threads=0):
+        """(o, d) of the rays the camera paths (sample, pixel) trace at bounce `bounce`; paths that ended earlier are
+        left out."""
+        k = np.ascontiguousarray(samples, np.int32)
+        m = np.ascontiguousarray(pixels, np.int32)
+        o, d = np.zeros((len(k), 3), np.float32), np.zeros((len(k), 3), np.float32)
+        alive = np.zeros(len(k), np.uint8)
+        self.lib.orc_capture_bounce_rays(self.h, rng, trig, seed, bounce, len(k), _p(k), _p(m), _p(o), _p(d), _p(alive), threads)
+        keep = alive != 0
+        return o[keep], d[keep]
 
     def sample_light(self, u4):
         u4 = _f32(u4)

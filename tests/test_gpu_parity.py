@@ -416,3 +416,13 @@ def test_cast_rays_equals_oracle_bit_exact(cornell, hp):
         import torch
         t = torch.zeros(64, device="cuda")
         ctx.cast_rays_dev(4, t, t, t, t, depth, t, block=512)
+
+
+def test_intersect_bounce_rays(cornell):
+    """The rays camera paths trace at bounce 3 (captured from the oracle: incoherent, starting on surfaces, many of
+    them grazing): closest hits bit-exact."""
+    sc, osc, ctx = cornell
+    pix = np.arange(512 * 512)[::2]
+    o, d = osc.bounce_rays(RNG_PHILOX, TRIG_PORTABLE, 3, np.full(len(pix), 1), pix)
+    assert len(o) > 50000
+    _check_hits(ctx.intersect(o, d), osc.intersect(o, d), "bounce-3 rays")

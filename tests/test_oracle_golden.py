@@ -416,3 +416,23 @@ def test_cast_rays_equals_cast_paths_on_the_camera_rays(oracle):
     assert st["paths"] == 500 and st["closest_queries"] >= 500 and np.isfinite(a).all() and (a >= 0).all() and a.max() > 0
     z, st = sc.cast_rays(RNG_PHILOX, TRIG_PORTABLE, 0, o, d, np.zeros(500), np.arange(500))
     assert not z.any() and st["closest_queries"] == 0
+
+
+def test_bounce_ray_capture(oracle):
+    """The incoherent ray batch of the traversal microbenchmark: bounce 0 gives the camera rays; the rays of bounce 3
+    start on surfaces of the scene (inside its bounding box) with unit directions, and fewer paths are alive."""
+    w, h = 32, 32
+    sc = oracle.cornell(w, h)
+    pix = np.arange(w * h)
+    k = np.full(w * h, 2)
+    o0, d0 = sc.bounce_rays(RNG_PHILOX, TRIG_PORTABLE, 0, k, pix)
+    bias = np.array([oracle.philox_uniform(m, 2, 0xFFFFFFFF, 0) for m in pix], np.float32).reshape(h, w)
+    o, d = primary_rays(w, h, CAM, sc.info()["cam_scale"], bias)
+    assert np.array_equal(o0, o) and np.array_equal(d0.view(np.uint32), d.view(np.uint32))
+    o3, d3 = sc.bounce_rays(RNG_PHILOX, TRIG_PORTABLE, 3, k, pix)
+    assert 0.3 * len(o0) < len(o3) < len(o0)
+    assert (o3.min(0) > -1).all() and (o3.max(0) < 560).all()
+    assert np.allclose(np.linalg.norm(d3.astype(np.float64), axis=1), 1.0, atol=1e-5)
+    # most of them hit the room again (its front is open)
+    prim, _ = sc.intersect(o3, d3)
+    assert 0.7 < (prim >= 0).mean() < 1.0

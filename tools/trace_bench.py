@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
 """Traversal-only microbenchmark: hpt_intersect_batch_dev on device-resident ray batches
-(primary grid / random closest / shadow / bounce-like rays), Mrays/s per batch type."""
+(primary grid / random closest / shadow / the rays camera paths trace at bounce 3, captured from the CPU
+restatement), Mrays/s per batch type."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import cudapathtracer_amd as hp
 from raybatches import primary_rays, random_rays, shadow_rays
+from orclib import Oracle, RNG_PHILOX, TRIG_PORTABLE
 
 sc = hp.Scene.CreateBuiltinScene(0, 20, 1024, 1024)
 ctx = hp.Context(0).upload(sc)
@@ -25,3 +27,10 @@ def run(name, o, d, sh=None, tm=None, reps=5):
 o, d = primary_rays(2048, 2048, (278, 273, -800), f["cam_scale"]); run("primary 2048^2", o, d)
 o, d = random_rays(n, 1); run("random closest", o, d)
 o, d, sh, tm = shadow_rays(n, 2); run("shadow", o, d, sh, tm)
+# (iv) incoherent rays as a render produces them: bounce 3 of the camera paths of one sample of a 1024^2 image
+osc = Oracle().cornell(1024, 1024)
+pix = np.arange(1024 * 1024)
+o, d = osc.bounce_rays(RNG_PHILOX, TRIG_PORTABLE, 3, np.zeros_like(pix), pix)
+reps = -(-n // len(o))
+o, d = np.tile(o, (reps, 1))[:n], np.tile(d, (reps, 1))[:n]
+run("bounce-3 rays", o, d)
