@@ -803,3 +803,16 @@ def test_cast_rays_on_other_scenes(hp, oracle, gpu_ctx, name):
         assert want.max() > 0
     finally:
         gpu_ctx.set_integrator(False, False)
+
+
+def test_random_scenes_sample():
+    """A sample of the randomised differential test (tools/fuzz_parity.py: random scenes, materials, sizes, depths,
+    sample ranges, seeds, modes, workgroup sizes, integrator options and BVH builders; accumulators, counters, hits,
+    occlusion and castRay radiance bit-exact against the oracle).  The tool itself runs thousands of cases."""
+    import io
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_parity
+    log = io.StringIO()
+    fuzz_parity.run(120, first=20000, out=log)
+    assert log.getvalue().count("  ok") == 120
