@@ -61,7 +61,12 @@ def build_case(rs, orc):
         kind = rs.choice(["soup", "soup", "box", "sphere", "bunny", "emitter"], p=[0.3, 0.2, 0.15, 0.2, 0.05, 0.1])
         if kind == "soup":
             n = int(rs.choice([1, 2, 7, 20, 31, 40, 90, 300]))
-            items.append(("tris", soup(rs, n, float(rs.choice([30.0, 120.0, 300.0]))), random_material(rs)))
+            tris = soup(rs, n, float(rs.choice([30.0, 120.0, 300.0])))
+            if n >= 7 and rs.rand() < 0.2:   # zero-area triangles: two equal vertices, a point
+                tris[1, 2] = tris[1, 1]
+                tris[4] = tris[4, 0]
+                what.append("degenerate")
+            items.append(("tris", tris, random_material(rs)))
             what.append("soup%d" % n)
         elif kind == "box":
             name = rs.choice(["shortbox", "tallbox"])
@@ -133,7 +138,18 @@ def _run(orc, ctx, cases, first, out):
         want, ost = osc.render(RNG_PHILOX, TRIG_PORTABLE, depth, spp, sample_begin=s0, seed=seed, fixed=True)
         ctx.stats_reset()
         ctx.accum_clear()
-        ctx.render(mode, block, depth, s0, spp)
+        # how the sample range is rendered: in one call; split over two calls (the sums do not depend on the split);
+        # by the entry point that allocates nothing; in streamed batches of a few thousand paths
+        how = rs.choice(["one call", "split", "static", "small batches"])
+        ctx.set_wavefront_capacity(int(rs.choice([4096, 20000])) if how == "small batches" else 1 << 24)
+        if how == "split" and spp > 1:
+            ctx.render(mode, block, depth, s0 + 1, spp - 1)
+            ctx.render(3 - mode, block, depth, s0, 1)
+        elif how == "static" and block <= 256:
+            ctx.render_static(mode, block, depth, s0, spp)
+        else:
+            ctx.render(mode, block, depth, s0, spp)
+        line += "  " + how
         got = ctx.accum_download()
         st = ctx.stats()
         if not np.array_equal(got, want):
@@ -142,6 +158,15 @@ def _run(orc, ctx, cases, first, out):
             fail("ray counters %r vs %r" % ((st["closest_queries"], st["shadow_queries"]), (ost["closest_queries"], ost["shadow_queries"])))
         # ray batches (a GPU-built tree may name another of several triangles that are hit at bitwise equal t)
         o, d = random_rays(4096, case)
+        # some axis-parallel rays (zero direction components: infinite reciprocals, the NaN-aware box test) and rays
+        # that start on the planes of the room
+        d[:256, rs.randint(0, 3)] = 0.0
+        d[:64, rs.randint(0, 3)] = 0.0
+        nrm = np.sqrt((d[:256].astype(np.float64) ** 2).sum(1))
+        keep = nrm > 0
+        d[:256][keep] = (d[:256][keep] / nrm[keep, None]).astype(np.float32)
+        d[:256][~keep] = (0, 0, 1)
+        o[256:512, 1] = 0.0
         gp, gt = ctx.intersect(o, d)
         wp, wt = osc.intersect(o, d)
         if not np.array_equal(gt.view(np.int64), wt.view(np.int64)):
