@@ -41,10 +41,14 @@ def soup(rs, n, size):
     return (c + (rs.rand(n, 3, 3) - 0.5) * size).astype(np.float32)
 
 
-def build_case(rs, orc):
+def build_case(rs, orc, big=False):
     """-> (hp scene, oracle scene, description)"""
-    w, h = int(rs.randint(6, 72)), int(rs.randint(6, 56))
-    depth = int(rs.choice([1, 2, 3, 5, 8, 12]))
+    if big:
+        w, h = int(rs.randint(64, 400)), int(rs.randint(64, 300))
+        depth = int(rs.choice([3, 8, 20]))
+    else:
+        w, h = int(rs.randint(6, 72)), int(rs.randint(6, 56))
+        depth = int(rs.choice([1, 2, 3, 5, 8, 12]))
     items = []  # ("tris", triangles, material) | ("sphere", centre, radius, material)
     what = []
     light = dict(type=0, emission=scenes.light_emission())
@@ -104,24 +108,25 @@ class Mismatch(AssertionError):
     pass
 
 
-def run(cases, first=0, out=sys.stdout):
-    """Runs cases [first, first + cases); raises Mismatch (message = the case line) at the first difference."""
+def run(cases, first=0, out=sys.stdout, big=False):
+    """Runs cases [first, first + cases); raises Mismatch (message = the case line) at the first difference.
+    big: images of 64..400 x 64..300 pixels with up to 40 samples (several work units per tile, chunks of samples)."""
     orc = Oracle()
     ctx = hp.Context(0)
     try:
-        _run(orc, ctx, cases, first, out)
+        _run(orc, ctx, cases, first, out, big)
     finally:
         ctx.close()
 
 
-def _run(orc, ctx, cases, first, out):
+def _run(orc, ctx, cases, first, out, big):
     t0 = time.time()
     for case in range(first, first + cases):
         rs = np.random.RandomState(1000 + case)
-        sc, osc, desc, depth, gpu_build = build_case(rs, orc)
+        sc, osc, desc, depth, gpu_build = build_case(rs, orc, big)
         rr, reg = bool(rs.rand() < 0.3), bool(rs.rand() < 0.3)
         seed = int(rs.choice([0, 1, 0xDEADBEEF]))
-        s0, spp = int(rs.choice([0, 0, 5, 1000])), int(rs.randint(1, 4))
+        s0, spp = int(rs.choice([0, 0, 5, 1000])), int(rs.choice([1, 7, 16, 17, 40]) if big else rs.randint(1, 4))
         mode, block = int(rs.choice([1, 2])), int(rs.choice([64, 100, 256, 256, 512]))
         ctx.upload(sc)
         ctx.set_integrator(rr, reg)
@@ -145,8 +150,10 @@ def _run(orc, ctx, cases, first, out):
         if how == "split" and spp > 1:
             ctx.render(mode, block, depth, s0 + 1, spp - 1)
             ctx.render(3 - mode, block, depth, s0, 1)
-        elif how == "static" and block <= 256:
-            ctx.render_static(mode, block, depth, s0, spp)
+        elif how == "static" and block <= 256 and ((sc.width + 7) // 8) * ((sc.height + 7) // 8) * 64 <= 1 << 18:
+            per_call = max(1, (1 << 18) // (((sc.width + 7) // 8) * ((sc.height + 7) // 8) * 64))   # its limit: 2^18 camera paths
+            for s in range(s0, s0 + spp, per_call):
+                ctx.render_static(mode, block, depth, s, min(per_call, s0 + spp - s))
         else:
             ctx.render(mode, block, depth, s0, spp)
         line += "  " + how
@@ -194,9 +201,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=200)
     ap.add_argument("--first", type=int, default=0)
+    ap.add_argument("--big", action="store_true", help="larger images and more samples per case")
     args = ap.parse_args()
     try:
-        run(args.cases, args.first)
+        run(args.cases, args.first, big=args.big)
     except Mismatch:
         sys.exit(1)
 
