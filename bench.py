@@ -124,9 +124,9 @@ def main():
     ap.add_argument("--traversal", default="reference", choices=["reference", "culled"],
                     help="reference = the reference's box/triangle tests exactly (the parity path); culled = near-first "
                          "order with distance culling for scenes of more than 64 triangles (opt-in, not bit-guaranteed)")
-    ap.add_argument("--bvh-build", default="host", choices=["host", "gpu"],
-                    help="host: the reference's tree (default); gpu: traversal records built on the device at upload "
-                         "(side measurement; scenes other than cornell)")
+    ap.add_argument("--bvh-build", default="host", choices=["host", "gpu", "sah"],
+                    help="host: the reference's tree (default); gpu: traversal records built on the device at upload; "
+                         "sah: host build with surface-area splits (side measurements; scenes other than cornell)")
     ap.add_argument("--scene", default="cornell", help="cornell (the headline workload) | bunny | heightfield:<n> "
                     "(side measurements of the other configurations; they never change the default line)")
     args = ap.parse_args()
@@ -192,6 +192,8 @@ def main():
         scene = scenes._assemble(scene_parts(args.scene), W, H, depth)
         if args.bvh_build == "gpu":
             scene.buildBVH(gpu=True)
+        elif args.bvh_build == "sah":
+            scene.buildBVH(sah=True)
     ctx = hp.Context(dev_index)
     if args.traversal == "culled":
         ctx.set_traversal(1)

@@ -194,7 +194,7 @@ def _stream(stream):
 
 
 TRAVERSAL_REFERENCE, TRAVERSAL_CULLED = 0, 1
-BVH_BUILD_HOST, BVH_BUILD_GPU = 0, 1
+BVH_BUILD_HOST, BVH_BUILD_GPU, BVH_BUILD_SAH = 0, 1, 2
 INTEGRATOR_RUSSIAN_ROULETTE, INTEGRATOR_REGULARIZE = 1, 2
 
 
@@ -235,7 +235,8 @@ class Scene:
     @staticmethod
     def CreateNamedScene(name, maxDepth=10, width=0, height=0, models_dir=DEFAULT_MODELS_DIR, bvh_build=BVH_BUILD_HOST):
         """Scene::CreateNamedScene: "cornell" | "bunny" | "glass" | "heightfield:<n>" | "file:<scene file>".
-        bvh_build=BVH_BUILD_GPU: the scene is flattened for the device-side build (Scene::default_bvh_build)."""
+        bvh_build=BVH_BUILD_GPU: the scene is flattened for the device-side build (Scene::default_bvh_build);
+        BVH_BUILD_SAH: host build with surface-area splits."""
         H = load_libraries()[1]
         h = C.c_void_p()
         _ckh(H.hpt_host_set_default_bvh_build(int(bvh_build)))
@@ -273,21 +274,29 @@ class Scene:
         _ckh(self._H.hpt_host_scene_add_sphere(self._h, c.ctypes.data, float(radius), C.byref(material)))
         self._built = False
 
-    def buildBVH(self, gpu=None):
+    def buildBVH(self, gpu=None, sah=False):
         """Scene::buildBVH.  gpu=True: only the light meshes' trees are built on the host and the traversal records
         are built on the device at upload (BVH_BUILD_GPU); gpu=False: the reference's two-level BVH on the host;
-        None keeps the scene's setting."""
-        if gpu is not None:
+        sah=True: the host build with surface-area splits for the top level and the non-emitting meshes
+        (BVH_BUILD_SAH; same leaves, fewer box tests per ray); None keeps the scene's setting."""
+        if sah:
+            _ckh(self._H.hpt_host_scene_set_bvh_build(self._h, BVH_BUILD_SAH))
+        elif gpu is not None:
             _ckh(self._H.hpt_host_scene_set_bvh_build(self._h, BVH_BUILD_GPU if gpu else BVH_BUILD_HOST))
         _ckh(self._H.hpt_host_scene_build(self._h))
         self._built = True
         return self
 
     @property
-    def gpu_build(self):
+    def bvh_build(self):
+        """How the scene was last built: BVH_BUILD_HOST, BVH_BUILD_GPU or BVH_BUILD_SAH."""
         b = C.c_int()
         _ckh(self._H.hpt_host_scene_bvh_build(self._h, C.byref(b)))
-        return b.value == BVH_BUILD_GPU
+        return b.value
+
+    @property
+    def gpu_build(self):
+        return self.bvh_build == BVH_BUILD_GPU
 
     def set_resolution(self, width, height):
         _ckh(self._H.hpt_host_scene_set_resolution(self._h, int(width), int(height)))
@@ -411,6 +420,8 @@ class Context:
         d = scene.describe() if isinstance(scene, Scene) else scene
         if bvh_build is None:
             bvh_build = BVH_BUILD_GPU if (isinstance(scene, Scene) and scene.gpu_build) else BVH_BUILD_HOST
+        if bvh_build == BVH_BUILD_SAH:   # a host build as far as the device library is concerned
+            bvh_build = BVH_BUILD_HOST
         _ck(self._L.hpt_set_bvh_build(self._h, int(bvh_build)))
         _ck(self._L.hpt_scene_upload(self._h, C.byref(d)))
         self.width, self.height = d.width, d.height

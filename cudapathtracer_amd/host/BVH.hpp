@@ -45,6 +45,16 @@ public:
 private:
     int32_t recursiveBuild(std::vector<int32_t>& order, size_t lo, size_t hi, const std::vector<Bounds3>& bounds,
                            const std::vector<Vec3>& centroids, const std::vector<float>& areas);
+    struct SahNode {
+        Bounds3 bounds;
+        float area = 0.f;
+        int32_t object = -1, first = -1, second = -1;
+        int32_t need = 0;  // stack entries a depth-first walk of the subtree needs
+    };
+    int32_t sahBuild(std::vector<SahNode>& tmp, std::vector<int32_t>& order, size_t lo, size_t hi, const std::vector<Bounds3>& bounds,
+                     const std::vector<Vec3>& centroids, const std::vector<float>& areas);
+    void sahEmit(const std::vector<SahNode>& tmp, int32_t root);
+    size_t sahSplit(std::vector<int32_t>& order, size_t lo, size_t hi, const std::vector<Bounds3>& bounds, const std::vector<Vec3>& centroids);
     void setMiss(int32_t node, int32_t val);
     std::vector<int32_t> right_child_;  // build-time only
 };

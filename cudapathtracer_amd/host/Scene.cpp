@@ -65,14 +65,15 @@ void Scene::buildBVH() {
     }
     std::vector<Object*> top_objects;
     for (const ObjectRef& o : objects) top_objects.push_back(o.sphere ? (Object*)spheres[o.index] : (Object*)meshes[o.index]);
-    bvh_owner_ = std::make_shared<BVHAccel>(top_objects, 1, BVHAccel::SplitMethod::NAIVE);
+    const bool sah = bvh_build == BvhBuild::Sah;
+    bvh_owner_ = std::make_shared<BVHAccel>(top_objects, 1, sah ? BVHAccel::SplitMethod::SAH : BVHAccel::SplitMethod::NAIVE);
     bvh = bvh_owner_.get();
     mesh_bvh_owner_.clear();
     mesh_bvhs.clear();
     for (MeshTriangle* m : meshes) {
         std::vector<Object*> tris(m->triangles.size());
         for (size_t i = 0; i < tris.size(); ++i) tris[i] = &m->triangles[i];
-        mesh_bvh_owner_.push_back(std::make_shared<BVHAccel>(tris, 1, BVHAccel::SplitMethod::NAIVE));
+        mesh_bvh_owner_.push_back(std::make_shared<BVHAccel>(tris, 1, sah && !m->material.emitting() ? BVHAccel::SplitMethod::SAH : BVHAccel::SplitMethod::NAIVE));
         mesh_bvhs.push_back(mesh_bvh_owner_.back().get());
     }
     // primitive ids count through the objects in Add order (a sphere is one primitive)
@@ -164,6 +165,7 @@ void Scene::buildBVH() {
         }
     }
 
+    fs->sah_build = sah;
     fillMaterialsAndLights(*fs);
     flat_ = fs;
 }

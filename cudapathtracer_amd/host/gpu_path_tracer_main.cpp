@@ -35,8 +35,8 @@ int main(int argc, char** argv) {
     try {
         // HPT_SCENE=bunny / glass / heightfield:<n> / file:<path> renders another scene than the reference's only one
         const char* which = getenv("HPT_SCENE");
-        if (const char* b = getenv("HPT_BVH"))  // "gpu": traversal records built on the device at upload
-            Scene::default_bvh_build = std::string(b) == "gpu" ? Scene::BvhBuild::Gpu : Scene::BvhBuild::Reference;
+        if (const char* b = getenv("HPT_BVH"))  // "gpu": traversal records built on the device at upload; "sah": surface-area splits on the host
+            Scene::default_bvh_build = std::string(b) == "gpu" ? Scene::BvhBuild::Gpu : std::string(b) == "sah" ? Scene::BvhBuild::Sah : Scene::BvhBuild::Reference;
         Scene scene = Scene::CreateNamedScene(which ? which : "cornell", maxDepth);
         if (const char* w = getenv("HPT_WIDTH")) scene.width = atoi(w);
         if (const char* h = getenv("HPT_HEIGHT")) scene.height = atoi(h);

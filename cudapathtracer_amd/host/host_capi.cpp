@@ -274,22 +274,28 @@ int hpt_host_render_iterative(const hpt_host_scene* s, int device, int spp, int 
     })
 }
 
+static bool to_bvh_build(int build, Scene::BvhBuild* out) {
+    if (build == HPT_BVH_BUILD_HOST) *out = Scene::BvhBuild::Reference;
+    else if (build == HPT_BVH_BUILD_GPU) *out = Scene::BvhBuild::Gpu;
+    else if (build == HPT_HOST_BVH_BUILD_SAH) *out = Scene::BvhBuild::Sah;
+    else return false;
+    return true;
+}
+
 int hpt_host_set_default_bvh_build(int build) {
-    if (build != HPT_BVH_BUILD_HOST && build != HPT_BVH_BUILD_GPU) return fail("build is neither HPT_BVH_BUILD_HOST nor HPT_BVH_BUILD_GPU");
-    Scene::default_bvh_build = build == HPT_BVH_BUILD_GPU ? Scene::BvhBuild::Gpu : Scene::BvhBuild::Reference;
+    if (!to_bvh_build(build, &Scene::default_bvh_build)) return fail("build is none of HPT_BVH_BUILD_HOST, HPT_BVH_BUILD_GPU, HPT_HOST_BVH_BUILD_SAH");
     return 0;
 }
 
 int hpt_host_scene_set_bvh_build(hpt_host_scene* s, int build) {
     if (!s) return fail("scene is null");
-    if (build != HPT_BVH_BUILD_HOST && build != HPT_BVH_BUILD_GPU) return fail("build is neither HPT_BVH_BUILD_HOST nor HPT_BVH_BUILD_GPU");
-    s->scene.bvh_build = build == HPT_BVH_BUILD_GPU ? Scene::BvhBuild::Gpu : Scene::BvhBuild::Reference;
+    if (!to_bvh_build(build, &s->scene.bvh_build)) return fail("build is none of HPT_BVH_BUILD_HOST, HPT_BVH_BUILD_GPU, HPT_HOST_BVH_BUILD_SAH");
     return 0;
 }
 
 int hpt_host_scene_bvh_build(const hpt_host_scene* s, int* build) {
     if (!s || !build) return fail("null argument");
-    GUARD(*build = s->scene.flat().gpu_build ? HPT_BVH_BUILD_GPU : HPT_BVH_BUILD_HOST)
+    GUARD(*build = s->scene.flat().gpu_build ? HPT_BVH_BUILD_GPU : s->scene.flat().sah_build ? HPT_HOST_BVH_BUILD_SAH : HPT_BVH_BUILD_HOST)
 }
 
 int hpt_host_scene_intersect(const hpt_host_scene* s, int device, size_t n, const float* o, const float* d, const uint8_t* shadow,

@@ -76,8 +76,14 @@ int hpt_host_render_iterative(const hpt_host_scene* s, int device, int spp, int 
  * onto devices[0].  iterative != 0: through PathTrace, sample iter on entry iter mod num_devices. */
 int hpt_host_render_devices(const hpt_host_scene* s, const int* devices, int num_devices, int spp, int max_depth,
                             int num_threads, int mode, int iterative, float* rgb, hpt_stats* stats);
-/* Scene::default_bvh_build: scenes created from now on flatten for HPT_BVH_BUILD_HOST (default) or HPT_BVH_BUILD_GPU
- * (include/hpt.h); the renderer picks the matching upload. */
+/* A third way to build the scene's tree, on the host like HPT_BVH_BUILD_HOST (the device library sees an ordinary
+ * host-built scene): BVHAccel::SplitMethod::SAH -- declared by the reference (common/BVH.hpp:28), implemented nowhere in it --
+ * for the top level and every mesh that does not emit, with the children ordered for a short traversal stack; emitting
+ * meshes keep the reference's tree (Scene::sampleLight descends it).  Same leaves as the reference's tree, so the
+ * guarantee of HPT_BVH_BUILD_GPU holds (include/hpt.h); fewer boxes are tested per ray. */
+#define HPT_HOST_BVH_BUILD_SAH 2
+/* Scene::default_bvh_build: scenes created from now on flatten for HPT_BVH_BUILD_HOST (default), HPT_BVH_BUILD_GPU
+ * (include/hpt.h) or HPT_HOST_BVH_BUILD_SAH; the renderer picks the matching upload. */
 int hpt_host_set_default_bvh_build(int build);
 /* Scene::bvh_build of one scene (takes effect at its next hpt_host_scene_build), and how the scene was last built */
 int hpt_host_scene_set_bvh_build(hpt_host_scene* s, int build);

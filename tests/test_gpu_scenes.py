@@ -374,11 +374,12 @@ def test_cli_renders_the_large_scene_configurations(tmp_path):
         assert data.startswith(b"P6\n%s %s\n255\n" % (res.encode(), res.encode())) and len(data) > 3 * int(res) ** 2
         body = np.frombuffer(data[-3 * int(res) ** 2:], np.uint8)
         assert body.max() == 255 and 20 < body.mean() < 200
-        # HPT_BVH=gpu: the same picture from traversal records built on the device
-        r = subprocess.run([os.path.join(root, "build", "gpu_path_tracer"), "4", "20", "256", "2"], cwd=str(tmp_path), env=dict(env, HPT_BVH="gpu"),
-                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=110)
-        assert r.returncode == 0, r.stdout
-        assert (tmp_path / "out" / "gpu" / (name + ".ppm")).read_bytes() == data
+        # HPT_BVH=gpu / sah: the same picture from traversal records built on the device / from surface-area splits
+        for build in ("gpu", "sah"):
+            r = subprocess.run([os.path.join(root, "build", "gpu_path_tracer"), "4", "20", "256", "2"], cwd=str(tmp_path), env=dict(env, HPT_BVH=build),
+                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=110)
+            assert r.returncode == 0, r.stdout
+            assert (tmp_path / "out" / "gpu" / (name + ".ppm")).read_bytes() == data, build
 
 
 @pytest.mark.parametrize("name", ["cornell", "heightfield4", "heightfield8", "bunny"])
@@ -743,11 +744,11 @@ def test_gpu_bvh_build_random_soups(hp, gpu_ctx):
         assert np.array_equal(gp_s >= 0, hp_s >= 0), "n = %d" % n
 
 
-@pytest.mark.parametrize("gpu_build", [False, True])
+@pytest.mark.parametrize("gpu_build", [False, True, "sah"])
 def test_bunny_full_resolution_render_matches_oracle_bit_exact(hp, oracle, gpu_ctx, gpu_build):
     """The bunny configuration at its benchmark resolution and depth (1024 x 1024, depth 20, streamed mode under the
     wave scheduler), 1 spp = 11 M rays: every accumulator and both ray counters equal the oracle's, on the host-built
-    tree and on device-built records."""
+    tree, on device-built records and on the host tree with surface-area splits."""
     from cudapathtracer_amd import scenes
     parts = scenes.bunny_in_cornell_parts()
     w = h = 1024
@@ -755,7 +756,7 @@ def test_bunny_full_resolution_render_matches_oracle_bit_exact(hp, oracle, gpu_c
     sc = hp.Scene(w, h, camPos=scenes.CORNELL_CAM, fov=40.0, maxDepth=depth)
     for _, tris, mat in parts:
         sc.Add(tris, hp.Material(**mat))
-    sc.buildBVH(gpu=gpu_build)
+    sc.buildBVH(sah=True) if gpu_build == "sah" else sc.buildBVH(gpu=gpu_build)
     osc = _oracle_scene(oracle, parts, w, h)
     gpu_ctx.upload(sc)
     gpu_ctx.stats_reset()
@@ -816,3 +817,69 @@ def test_random_scenes_sample():
     log = io.StringIO()
     fuzz_parity.run(120, first=20000, out=log)
     assert log.getvalue().count("  ok") == 120
+
+
+@pytest.mark.parametrize("name", ["bunny", "heightfield128", "heightfield8", "heightfield4", "spheres", "glass"])
+def test_sah_build_renders_the_reference_results(hp, oracle, gpu_ctx, name):
+    """Scene::BvhBuild::Sah (surface-area splits on the host for the top level and the non-emitting meshes, the
+    reference's leaves): closest distances, occlusion answers, ray counters and rendered images equal the oracle's bit
+    for bit in every traversal variant; a primitive id may differ only between triangles hit at bitwise the same
+    distance; the traversal stack is no deeper than the reference tree's."""
+    from cudapathtracer_amd import scenes
+    w, h, depth, spp = 56, 40, 8, 2
+    if name == "spheres":
+        sc, osc = _sphere_scene(hp, oracle, w, h, depth, big=True)
+    else:
+        parts = (scenes.bunny_in_cornell_parts() if name == "bunny" else scenes.glass_cornell_parts() if name == "glass"
+                 else scenes.heightfield_in_cornell_parts(int(name[11:])))
+        sc = hp.Scene(w, h, camPos=scenes.CORNELL_CAM, fov=40.0, maxDepth=depth)
+        for _, tris, mat in parts:
+            sc.Add(tris, hp.Material(**mat))
+        sc.buildBVH()
+        osc = _oracle_scene(oracle, parts, w, h)
+    gpu_ctx.upload(sc)
+    ref_info, ref_variant = gpu_ctx.build_info(), gpu_ctx.stats()["variant"]
+    sc.buildBVH(sah=True)
+    assert sc.bvh_build == hp.BVH_BUILD_SAH
+    gpu_ctx.upload(sc)
+    info = gpu_ctx.build_info()
+    assert gpu_ctx.stats()["variant"] == ref_variant and info["gpu_build_ms"] == 0 and info["records"] == ref_info["records"]
+    assert info["stack_depth"] <= ref_info["stack_depth"], (info, ref_info)
+    ties = 0
+    o, d = primary_rays(192, 192, scenes.CORNELL_CAM, osc.info()["cam_scale"])
+    ties += _hits_equal_up_to_ties(gpu_ctx.intersect(o, d), osc.intersect(o, d), "primary")
+    o, d = random_rays(1 << 17, 41)
+    ties += _hits_equal_up_to_ties(gpu_ctx.intersect(o, d), osc.intersect(o, d), "random")
+    assert ties <= 4, "%d primitive ids differ at equal distances" % ties
+    _same_occlusion(gpu_ctx, osc, *_shadow_batch(1 << 16, 42, down=name.startswith("heightfield")))
+    want_acc, ost = osc.render(RNG_PHILOX, TRIG_PORTABLE, depth, spp, fixed=True)
+    for mode in (1, 2):
+        gpu_ctx.stats_reset()
+        gpu_ctx.accum_clear()
+        gpu_ctx.render(mode, 256, depth, 0, spp)
+        got = gpu_ctx.resolve(spp)
+        st = gpu_ctx.stats()
+        assert (st["closest_queries"], st["shadow_queries"]) == (ost["closest_queries"], ost["shadow_queries"])
+        assert np.array_equal(got.view(np.int32), oracle.resolve(want_acc, spp).view(np.int32)), "mode %d" % mode
+
+
+def test_sah_build_of_the_million_triangle_scene(hp, gpu_ctx):
+    """The 1.0 M-triangle height field with surface-area splits: closest distances, occlusion answers and a rendered
+    image equal those of the reference tree on the same GPU; fewer boxes are tested (the counting build says how many
+    in tools/count_tests.py; here: the stack is no deeper)."""
+    sc = hp.Scene.CreateNamedScene("heightfield:708", 5, 64, 64, bvh_build=hp.BVH_BUILD_SAH)
+    gpu_ctx.upload(sc)
+    info = gpu_ctx.build_info()
+    o, d = random_rays(1 << 18, 51)
+    so, sd, sh, tm = _shadow_batch(1 << 17, 52, down=True)
+    got, got_s = gpu_ctx.intersect(o, d), gpu_ctx.intersect(so, sd, sh, tm)
+    gpu_ctx.accum_clear()
+    gpu_ctx.render(2, 256, 5, 0, 1)
+    img = gpu_ctx.accum_download()
+    gpu_ctx.upload(hp.Scene.CreateNamedScene("heightfield:708", 5, 64, 64))
+    assert info["stack_depth"] <= gpu_ctx.build_info()["stack_depth"] and info["records"] == gpu_ctx.build_info()["records"]
+    assert _hits_equal_up_to_ties(got, gpu_ctx.intersect(o, d), "1M random") <= 8
+    assert np.array_equal(got_s[0] >= 0, gpu_ctx.intersect(so, sd, sh, tm)[0] >= 0)
+    gpu_ctx.accum_clear()
+    gpu_ctx.render(2, 256, 5, 0, 1)
+    assert np.array_equal(img, gpu_ctx.accum_download())

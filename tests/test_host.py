@@ -565,3 +565,67 @@ def test_image_diff_tool(hp, tmp_path):
     assert r.returncode == 1 and "1 of 96 pixels differ" in r.stdout and ("rmse %.6g" % want) in r.stdout
     r = subprocess.run([sys.executable, tool, str(tmp_path / "a.ppm"), str(tmp_path / "b.ppm")], capture_output=True, text=True)
     assert r.returncode == 0 and "1 of 96 pixels differ" in r.stdout
+
+
+def _tree_facts(f):
+    """Checks the flattened pre-order tree of a scene (left child = next node, right child = the left child's miss
+    link, leaves carry triangle records) and returns (surface-area cost, stack entries a depth-first walk needs,
+    leaf triangle indices in order)."""
+    nodes = f["nodes"]
+    n = len(nodes)
+    lo, hi = nodes[:, 0:3].astype(np.float64), nodes[:, 4:7].astype(np.float64)
+    miss, tri = nodes[:, 3].view(np.int32), nodes[:, 7].view(np.int32)
+    leaf = tri >= 0
+    area = 2 * ((hi - lo)[:, 0] * (hi - lo)[:, 1] + (hi - lo)[:, 1] * (hi - lo)[:, 2] + (hi - lo)[:, 2] * (hi - lo)[:, 0])
+    need = np.zeros(n, np.int64)
+    assert miss[0] == n
+    for i in range(n - 1, -1, -1):      # children follow their parent in pre-order
+        if leaf[i]:
+            continue
+        left, right = i + 1, miss[i + 1]
+        assert i < left < right < n and miss[right] == miss[i], i
+        assert np.array_equal(np.minimum(lo[left], lo[right]), lo[i]) and np.array_equal(np.maximum(hi[left], hi[right]), hi[i]), i
+        need[i] = max(need[left] + (0 if leaf[right] else 1), need[right])
+    leaves = tri[leaf]
+    assert sorted(leaves.tolist()) == list(range(len(f["tris"])))   # every triangle record in exactly one leaf
+    return float(area[~leaf].sum()), int(need[0]), leaves
+
+
+@pytest.mark.parametrize("name", ["bunny", "heightfield:40", "glass"])
+def test_sah_build(hp, name):
+    """Scene::BvhBuild::Sah (BVHAccel::SplitMethod::SAH, declared but not implemented by the reference,
+    common/BVH.hpp:28): a valid two-level tree over the same triangle records with a lower surface-area cost than the
+    reference's median splits, a traversal stack no deeper than log2 of the triangle count, the emitting mesh's
+    subtree (which Scene::sampleLight descends) and all light tables untouched; deterministic."""
+    ref = hp.Scene.CreateNamedScene(name, 5, 64, 64)
+    sah = hp.Scene.CreateNamedScene(name, 5, 64, 64, bvh_build=hp.BVH_BUILD_SAH)
+    assert ref.bvh_build == hp.BVH_BUILD_HOST and sah.bvh_build == hp.BVH_BUILD_SAH and not sah.gpu_build
+    fr, fs = ref.flat_arrays(), sah.flat_arrays()
+    cost_r, need_r, leaves_r = _tree_facts(fr)
+    cost_s, need_s, leaves_s = _tree_facts(fs)
+    nt = len(fr["tris"])
+    assert cost_s < (0.9 if name != "glass" else 1.0001) * cost_r, (cost_s, cost_r)
+    assert need_s <= int(np.log2(nt)) and need_s <= need_r + 1, (need_s, need_r)
+    # the same triangles (by primitive id) with the same records
+    order_r, order_s = np.argsort(fr["prim_of_tri"]), np.argsort(fs["prim_of_tri"])
+    assert np.array_equal(fr["prim_of_tri"][order_r], fs["prim_of_tri"][order_s])
+    assert np.array_equal(fr["tris"][order_r][:, :15].view(np.uint32), fs["tris"][order_s][:, :15].view(np.uint32))
+    # lights: same areas and materials; the light mesh's subtree has the reference's shape, areas and leaf order
+    assert [(a, ra, m) for a, ra, _, m in fr["lights"]] == [(a, ra, m) for a, ra, _, m in fs["lights"]]
+    assert (fr["sum_light_area"], fr["sum_light_power"]) == (fs["sum_light_area"], fs["sum_light_power"])
+    for (_, _, root_r, _), (_, _, root_s, _) in zip(fr["lights"], fs["lights"]):
+        end_r = fr["nodes"][root_r, 3].view(np.int32)
+        k = int(end_r) - root_r
+        assert np.array_equal(fr["nodes"][root_r:root_r + k, [0, 1, 2, 4, 5, 6]], fs["nodes"][root_s:root_s + k, [0, 1, 2, 4, 5, 6]])
+        assert np.array_equal(fr["node_area"][root_r:root_r + k], fs["node_area"][root_s:root_s + k])
+        tr, ts = fr["nodes"][root_r:root_r + k, 7].view(np.int32), fs["nodes"][root_s:root_s + k, 7].view(np.int32)
+        assert np.array_equal(tr >= 0, ts >= 0)
+        assert np.array_equal(fr["prim_of_tri"][tr[tr >= 0]], fs["prim_of_tri"][ts[ts >= 0]])
+    again = hp.Scene.CreateNamedScene(name, 5, 64, 64, bvh_build=hp.BVH_BUILD_SAH).flat_arrays()
+    assert np.array_equal(again["nodes"].view(np.uint32), fs["nodes"].view(np.uint32))
+    # switching a scene back and forth
+    sah.buildBVH(gpu=False)
+    assert sah.bvh_build == hp.BVH_BUILD_HOST
+    assert np.array_equal(sah.flat_arrays()["nodes"].view(np.uint32), fr["nodes"].view(np.uint32))
+    sah.buildBVH(sah=True)
+    assert np.array_equal(sah.flat_arrays()["nodes"].view(np.uint32), fs["nodes"].view(np.uint32))

@@ -5,7 +5,7 @@
 
 Every case draws a scene (the Cornell shell or a bare light, plus random triangle soups, boxes of the reference's
 Cornell box, the bunny and spheres, with random Lambertian / microfacet / glass materials and sometimes a second
-emitter), an image size, depth, sample range, seed, render mode, workgroup size, integrator options and BVH builder,
+emitter), an image size, depth, sample range, seed, render mode, workgroup size, integrator options and BVH builder (reference / device / SAH),
 and compares -- bit for bit -- the fixed-point accumulators and the ray counters of hpt_render with the oracle's, the
 closest hits of a random ray batch, the occlusion answers of a shadow batch and the radiance of hpt_cast_rays.
 Prints one line per case and stops at the first difference with the case's seed (exit status 1)."""
@@ -98,10 +98,11 @@ def build_case(rs, orc, big=False):
         else:
             sc.AddSphere(it[1], it[2], hp.Material(**it[3]))
             osc.add_sphere(it[1], it[2], Material.make(**it[3]))
-    gpu_build = bool(rs.rand() < 0.3)
-    sc.buildBVH(gpu=gpu_build)
+    build = rs.choice(["host", "gpu", "sah"], p=[0.5, 0.25, 0.25])
+    sc.buildBVH(sah=True) if build == "sah" else sc.buildBVH(gpu=bool(build == "gpu"))
     osc.build()
-    return sc, osc, "%dx%d d%d %s%s" % (w, h, depth, "+".join(what), " gpu-bvh" if gpu_build else ""), depth, gpu_build
+    # gpu_build: the tree is not the reference's (ids may differ where several triangles are hit at one distance)
+    return sc, osc, "%dx%d d%d %s%s" % (w, h, depth, "+".join(what), "" if build == "host" else " %s-bvh" % build), depth, build != "host"
 
 
 class Mismatch(AssertionError):
