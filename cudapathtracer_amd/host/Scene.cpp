@@ -106,6 +106,33 @@ void Scene::buildBVH() {
     fs->prim_of_tri.resize(num_tris);
     fs->mesh_root.assign(meshes.size(), -1);
 
+    // A triangle's record index is its rank in the REFERENCE's traversal order (top-level leaves in the order the
+    // reference's top-level tree meets them, then the mesh's leaves in the order its reference tree meets them),
+    // whatever tree is emitted: among triangles hit at bitwise the same distance the kernels keep the lowest record
+    // index, which is then the triangle the reference's strict `<` keeps (common/BVH.hpp:128-137).  For the
+    // reference build these are the trees just built; the SAH build makes the reference's trees once more for it.
+    std::vector<int32_t> rec_base(objects.size(), 0);
+    std::vector<std::vector<int32_t>> rec_of_tri(meshes.size());
+    {
+        std::shared_ptr<BVHAccel> top_ref = sah ? std::make_shared<BVHAccel>(top_objects, 1, BVHAccel::SplitMethod::NAIVE) : bvh_owner_;
+        int32_t next = 0;
+        for (int32_t obj : top_ref->leafOrder()) {
+            rec_base[obj] = next;
+            next += objects[obj].sphere ? 1 : meshes[objects[obj].index]->num_triangles;
+        }
+        for (size_t k = 0; k < meshes.size(); ++k) {
+            std::shared_ptr<BVHAccel> ref = mesh_bvh_owner_[k];
+            if (ref->splitMethod != BVHAccel::SplitMethod::NAIVE) {
+                std::vector<Object*> tris(meshes[k]->triangles.size());
+                for (size_t i = 0; i < tris.size(); ++i) tris[i] = &meshes[k]->triangles[i];
+                ref = std::make_shared<BVHAccel>(tris, 1, BVHAccel::SplitMethod::NAIVE);
+            }
+            const std::vector<int32_t> order = ref->leafOrder();
+            rec_of_tri[k].assign(order.size(), 0);
+            for (size_t i = 0; i < order.size(); ++i) rec_of_tri[k][(size_t)order[i]] = (int32_t)i;
+        }
+    }
+
     auto write_node = [&](int32_t g, const Bounds3& b, int32_t miss, int32_t tri, float area) {
         float* n = fs->nodes.data + 8ull * g;
         n[0] = b.pMin.x; n[1] = b.pMin.y; n[2] = b.pMin.z; put_int(n + 3, miss);
@@ -113,7 +140,6 @@ void Scene::buildBVH() {
         fs->node_area.data[g] = area;
     };
 
-    int32_t next_tri = 0;
     for (size_t t = 0; t < top.size(); ++t) {
         const FlatNode& tn = top[t];
         const int32_t g0 = top_to_global[t];
@@ -124,7 +150,7 @@ void Scene::buildBVH() {
         const int obj = tn.object;  // index into `objects` = material index
         if (objects[obj].sphere) {
             const Sphere* sp = spheres[objects[obj].index];
-            const int32_t rec = next_tri++;
+            const int32_t rec = rec_base[obj];
             float* r = fs->tris.data + 16ull * rec;
             r[0] = sp->center.x; r[1] = sp->center.y; r[2] = sp->center.z; r[3] = 0.f;
             r[4] = sp->radius; r[5] = sp->radius2; r[6] = 0.f; put_int(r + 7, obj);
@@ -149,7 +175,7 @@ void Scene::buildBVH() {
             const FlatNode& n = mn[i];
             int32_t tri = -1;
             if (n.object >= 0) {
-                tri = next_tri++;
+                tri = rec_base[obj] + rec_of_tri[k][(size_t)n.object];
                 const Triangle& T = mesh->triangles[n.object];
                 float* r = fs->tris.data + 16ull * tri;
                 r[0] = T.v0.x; r[1] = T.v0.y; r[2] = T.v0.z; r[3] = T.area;

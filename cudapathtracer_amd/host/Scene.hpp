@@ -77,10 +77,12 @@ public:
     // by the surface-area heuristic (BVHAccel::SplitMethod::SAH, which the reference declares without implementing,
     // common/BVH.hpp:28) and their children ordered so that the traversal stack stays short; emitting meshes keep the
     // reference's tree, which Scene::sampleLight descends.  The leaves (one triangle each, same boxes) are the
-    // reference's, so the guarantee is HPT_BVH_BUILD_GPU's: every ray with finite reciprocal direction components
-    // tests the same triangles and gets the same closest distance and occlusion answer; of several triangles hit at
-    // bitwise equal distance another one may be named.  Fewer boxes are tested on the way: 9-14 % more rays per
-    // second on the bunny and the 1.0 M-triangle height field.
+    // reference's, so every ray with finite reciprocal direction components tests the same triangles and gets the
+    // same closest distance and occlusion answer; the triangle records stay in the reference's traversal order (the
+    // reference's trees are built once more for that), so of several triangles hit at bitwise equal distance the one
+    // the reference names is named.  Fewer boxes are tested on the way: 9-14 % more rays per second on the bunny and
+    // the 1.0 M-triangle height field.  What is not covered: a ray with a zero direction component whose origin lies
+    // exactly on a box plane (0 * inf = NaN in the slab test), where the reference's answer depends on its tree.
     enum class BvhBuild { Reference, Gpu, Sah };
     static BvhBuild default_bvh_build;  // what new scenes start with (the built-in scenes build inside their factory)
     BvhBuild bvh_build = default_bvh_build;

@@ -79,8 +79,9 @@ int hpt_host_render_devices(const hpt_host_scene* s, const int* devices, int num
 /* A third way to build the scene's tree, on the host like HPT_BVH_BUILD_HOST (the device library sees an ordinary
  * host-built scene): BVHAccel::SplitMethod::SAH -- declared by the reference (common/BVH.hpp:28), implemented nowhere in it --
  * for the top level and every mesh that does not emit, with the children ordered for a short traversal stack; emitting
- * meshes keep the reference's tree (Scene::sampleLight descends it).  Same leaves as the reference's tree, so the
- * guarantee of HPT_BVH_BUILD_GPU holds (include/hpt.h); fewer boxes are tested per ray. */
+ * meshes keep the reference's tree (Scene::sampleLight descends it).  Same leaves as the reference's tree and the
+ * triangle records in the reference's traversal order: distances, occlusion answers AND primitive ids are the
+ * reference's for every ray with finite reciprocal direction components; fewer boxes are tested per ray. */
 #define HPT_HOST_BVH_BUILD_SAH 2
 /* Scene::default_bvh_build: scenes created from now on flatten for HPT_BVH_BUILD_HOST (default), HPT_BVH_BUILD_GPU
  * (include/hpt.h) or HPT_HOST_BVH_BUILD_SAH; the renderer picks the matching upload. */

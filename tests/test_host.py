@@ -606,10 +606,12 @@ def test_sah_build(hp, name):
     nt = len(fr["tris"])
     assert cost_s < (0.9 if name != "glass" else 1.0001) * cost_r, (cost_s, cost_r)
     assert need_s <= int(np.log2(nt)) and need_s <= need_r + 1, (need_s, need_r)
-    # the same triangles (by primitive id) with the same records
-    order_r, order_s = np.argsort(fr["prim_of_tri"]), np.argsort(fs["prim_of_tri"])
-    assert np.array_equal(fr["prim_of_tri"][order_r], fs["prim_of_tri"][order_s])
-    assert np.array_equal(fr["tris"][order_r][:, :15].view(np.uint32), fs["tris"][order_s][:, :15].view(np.uint32))
+    # the triangle records are the reference build's, in the reference's traversal order (the kernels' tie rule --
+    # lowest record index among equal distances -- then names the triangle the reference names); only the tree differs
+    assert np.array_equal(fr["prim_of_tri"], fs["prim_of_tri"])
+    assert np.array_equal(fr["tris"].view(np.uint32), fs["tris"].view(np.uint32))
+    assert np.array_equal(fr["tri_v12"].view(np.uint32), fs["tri_v12"].view(np.uint32))
+    assert not np.array_equal(leaves_r, leaves_s) or name == "glass"
     # lights: same areas and materials; the light mesh's subtree has the reference's shape, areas and leaf order
     assert [(a, ra, m) for a, ra, _, m in fr["lights"]] == [(a, ra, m) for a, ra, _, m in fs["lights"]]
     assert (fr["sum_light_area"], fr["sum_light_power"]) == (fs["sum_light_area"], fs["sum_light_power"])

@@ -101,8 +101,9 @@ def build_case(rs, orc, big=False):
     build = rs.choice(["host", "gpu", "sah"], p=[0.5, 0.25, 0.25])
     sc.buildBVH(sah=True) if build == "sah" else sc.buildBVH(gpu=bool(build == "gpu"))
     osc.build()
-    # gpu_build: the tree is not the reference's (ids may differ where several triangles are hit at one distance)
-    return sc, osc, "%dx%d d%d %s%s" % (w, h, depth, "+".join(what), "" if build == "host" else " %s-bvh" % build), depth, build != "host"
+    # gpu_build: device-built records keep their own leaf order (ids may differ where several triangles are hit at one
+    # distance); the SAH tree keeps the reference's record order, ids included
+    return sc, osc, "%dx%d d%d %s%s" % (w, h, depth, "+".join(what), "" if build == "host" else " %s-bvh" % build), depth, build == "gpu"
 
 
 class Mismatch(AssertionError):
