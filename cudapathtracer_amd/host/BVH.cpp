@@ -3,7 +3,7 @@
 #include <algorithm>
 #include <stdexcept>
 
-BVHAccel::BVHAccel(const std::vector<Object*>& p, int maxPrims, SplitMethod method)
+BVHAccel::BVHAccel(const std::vector<Object*>& p, int maxPrims, SplitMethod method, const std::vector<int32_t>* leaf_need)
     : maxPrimsInNode(std::min(255, maxPrims)), splitMethod(method) {
     if (p.empty()) return;
     const size_t n = p.size();
@@ -22,7 +22,7 @@ BVHAccel::BVHAccel(const std::vector<Object*>& p, int maxPrims, SplitMethod meth
     if (method == SplitMethod::SAH) {
         std::vector<SahNode> tmp;
         tmp.reserve(2 * n);
-        const int32_t root = sahBuild(tmp, order, 0, n, bounds, centroids, areas);
+        const int32_t root = sahBuild(tmp, order, 0, n, bounds, centroids, areas, leaf_need);
         sahEmit(tmp, root);
     } else {
         recursiveBuild(order, 0, n, bounds, centroids, areas);
@@ -138,7 +138,7 @@ size_t BVHAccel::sahSplit(std::vector<int32_t>& order, size_t lo, size_t hi, con
 // no tree over n leaves needs more than log2(n) entries -- never more than the balanced median-split tree, however
 // uneven the SAH splits are (the per-lane stacks of the traversal kernels live in LDS and bound the occupancy).
 int32_t BVHAccel::sahBuild(std::vector<SahNode>& tmp, std::vector<int32_t>& order, size_t lo, size_t hi, const std::vector<Bounds3>& bounds,
-                           const std::vector<Vec3>& centroids, const std::vector<float>& areas) {
+                           const std::vector<Vec3>& centroids, const std::vector<float>& areas, const std::vector<int32_t>* leaf_need) {
     const int32_t self = (int32_t)tmp.size();
     tmp.emplace_back();
     const size_t count = hi - lo;
@@ -147,11 +147,15 @@ int32_t BVHAccel::sahBuild(std::vector<SahNode>& tmp, std::vector<int32_t>& orde
         tmp[self].bounds = bounds[obj];
         tmp[self].object = obj;
         tmp[self].area = areas[obj];
+        if (leaf_need && (*leaf_need)[(size_t)obj] >= 0) {
+            tmp[self].need = (*leaf_need)[(size_t)obj];
+            tmp[self].heavy = true;
+        }
         return self;
     }
     const size_t mid = count == 2 ? lo + 1 : sahSplit(order, lo, hi, bounds, centroids);
-    const int32_t a = sahBuild(tmp, order, lo, mid, bounds, centroids, areas);
-    const int32_t b = sahBuild(tmp, order, mid, hi, bounds, centroids, areas);
+    const int32_t a = sahBuild(tmp, order, lo, mid, bounds, centroids, areas, leaf_need);
+    const int32_t b = sahBuild(tmp, order, mid, hi, bounds, centroids, areas, leaf_need);
     const bool a_first = tmp[a].need <= tmp[b].need;
     SahNode& n = tmp[self];
     n.first = a_first ? a : b;
@@ -159,8 +163,8 @@ int32_t BVHAccel::sahBuild(std::vector<SahNode>& tmp, std::vector<int32_t>& orde
     n.bounds = Union(tmp[n.first].bounds, tmp[n.second].bounds);
     n.area = tmp[n.first].area + tmp[n.second].area;
     // leaves are tested, not pushed: only an interior second child occupies a stack entry
-    const int32_t held = tmp[n.second].object >= 0 ? 0 : 1;
-    n.need = std::max(tmp[n.first].need + held, tmp[n.second].need);
+    n.heavy = true;
+    n.need = std::max(tmp[n.first].need + (tmp[n.second].heavy ? 1 : 0), tmp[n.second].need);
     return self;
 }
 
@@ -200,6 +204,16 @@ void BVHAccel::setMiss(int32_t root, int32_t val) {
         stack.emplace_back(left, right);
         stack.emplace_back(right, miss);
     }
+}
+
+int32_t BVHAccel::stackNeed() const {
+    std::vector<int32_t> need(nodes.size(), 0);
+    for (size_t i = nodes.size(); i-- > 0;) {  // children follow their parent in pre-order
+        if (nodes[i].object >= 0) continue;
+        const size_t left = i + 1, right = (size_t)nodes[left].miss;
+        need[i] = std::max(need[left] + (nodes[right].object >= 0 ? 0 : 1), need[right]);
+    }
+    return nodes.empty() ? 0 : need[0];
 }
 
 std::vector<int32_t> BVHAccel::leafOrder() const {

@@ -31,7 +31,14 @@ public:
     enum class SplitMethod { NAIVE, SAH };
 
     // primitives are borrowed for the duration of the constructor
-    BVHAccel(const std::vector<Object*>& p, int maxPrimsInNode = 1, SplitMethod splitMethod = SplitMethod::NAIVE);
+    // leaf_need (SAH only, optional): per primitive, the stack entries of the subtree that will stand in its leaf's
+    // place once the tree is flattened (a mesh under the top level); -1 = the leaf stays a leaf.  The child order
+    // takes it into account.
+    BVHAccel(const std::vector<Object*>& p, int maxPrimsInNode = 1, SplitMethod splitMethod = SplitMethod::NAIVE,
+             const std::vector<int32_t>* leaf_need = nullptr);
+    // stack entries a depth-first walk needs that descends into a node's first child and keeps the second, if it is
+    // not a leaf, on its stack
+    int32_t stackNeed() const;
 
     Bounds3 WorldBound() const { return nodes.empty() ? Bounds3() : nodes[0].bounds; }
     float rootArea() const { return nodes.empty() ? 0.f : nodes[0].area; }
@@ -50,9 +57,10 @@ private:
         float area = 0.f;
         int32_t object = -1, first = -1, second = -1;
         int32_t need = 0;  // stack entries a depth-first walk of the subtree needs
+        bool heavy = false;  // an interior node, or a leaf a subtree will replace: occupies a stack entry while it waits
     };
     int32_t sahBuild(std::vector<SahNode>& tmp, std::vector<int32_t>& order, size_t lo, size_t hi, const std::vector<Bounds3>& bounds,
-                     const std::vector<Vec3>& centroids, const std::vector<float>& areas);
+                     const std::vector<Vec3>& centroids, const std::vector<float>& areas, const std::vector<int32_t>* leaf_need);
     void sahEmit(const std::vector<SahNode>& tmp, int32_t root);
     size_t sahSplit(std::vector<int32_t>& order, size_t lo, size_t hi, const std::vector<Bounds3>& bounds, const std::vector<Vec3>& centroids);
     void setMiss(int32_t node, int32_t val);

@@ -63,11 +63,34 @@ void Scene::buildBVH() {
         buildForGpu();
         return;
     }
-    std::vector<Object*> top_objects;
-    for (const ObjectRef& o : objects) top_objects.push_back(o.sphere ? (Object*)spheres[o.index] : (Object*)meshes[o.index]);
+    // Reference: the top level over the objects, every mesh a subtree of its own (common/Scene.cpp:9-23).
+    // Sah: surface-area splits for the top level and for every mesh that does not emit (an emitting mesh keeps the
+    // reference's subtree: Scene::sampleLight descends it).  Small non-emitting meshes (walls, boxes: up to
+    // kExplode triangles) enter the top level as individual triangles instead of as one object each: their
+    // room-sized boxes would otherwise all be entered by every ray.
     const bool sah = bvh_build == BvhBuild::Sah;
-    bvh_owner_ = std::make_shared<BVHAccel>(top_objects, 1, sah ? BVHAccel::SplitMethod::SAH : BVHAccel::SplitMethod::NAIVE);
-    bvh = bvh_owner_.get();
+    constexpr size_t kExplode = 64;
+    struct TopItem {
+        int obj;  // index into `objects`
+        int tri;  // >= 0: that triangle of the mesh; -1: the whole object (a sphere, or a mesh spliced in as a subtree)
+    };
+    std::vector<TopItem> items;
+    std::vector<Object*> top_objects, ref_objects;
+    for (size_t k = 0; k < objects.size(); ++k) {
+        const ObjectRef& o = objects[k];
+        Object* whole = o.sphere ? (Object*)spheres[o.index] : (Object*)meshes[o.index];
+        ref_objects.push_back(whole);
+        if (sah && !o.sphere && !meshes[o.index]->material.emitting() && meshes[o.index]->triangles.size() <= kExplode) {
+            MeshTriangle* m = meshes[o.index];
+            for (size_t i = 0; i < m->triangles.size(); ++i) {
+                items.push_back({(int)k, (int)i});
+                top_objects.push_back(&m->triangles[i]);
+            }
+        } else {
+            items.push_back({(int)k, -1});
+            top_objects.push_back(whole);
+        }
+    }
     mesh_bvh_owner_.clear();
     mesh_bvhs.clear();
     for (MeshTriangle* m : meshes) {
@@ -76,6 +99,14 @@ void Scene::buildBVH() {
         mesh_bvh_owner_.push_back(std::make_shared<BVHAccel>(tris, 1, sah && !m->material.emitting() ? BVHAccel::SplitMethod::SAH : BVHAccel::SplitMethod::NAIVE));
         mesh_bvhs.push_back(mesh_bvh_owner_.back().get());
     }
+    // the top level orders its children by the stack their subtrees need, the meshes' subtrees included
+    std::vector<int32_t> leaf_need(items.size(), -1);
+    for (size_t i = 0; i < items.size(); ++i) {
+        const ObjectRef& o = objects[(size_t)items[i].obj];
+        if (items[i].tri < 0 && !o.sphere && meshes[o.index]->triangles.size() > 1) leaf_need[i] = mesh_bvhs[o.index]->stackNeed();
+    }
+    bvh_owner_ = std::make_shared<BVHAccel>(top_objects, 1, sah ? BVHAccel::SplitMethod::SAH : BVHAccel::SplitMethod::NAIVE, sah ? &leaf_need : nullptr);
+    bvh = bvh_owner_.get();
     // primitive ids count through the objects in Add order (a sphere is one primitive)
     std::vector<int32_t> object_base(objects.size());
     int32_t base = 0;
@@ -90,8 +121,8 @@ void Scene::buildBVH() {
     int32_t cursor = 0;
     for (size_t t = 0; t < top.size(); ++t) {
         top_to_global[t] = cursor;
-        const bool mesh_leaf = top[t].object >= 0 && !objects[top[t].object].sphere;
-        cursor += mesh_leaf ? (int32_t)mesh_bvhs[objects[top[t].object].index]->nodes.size() : 1;
+        const bool mesh_leaf = top[t].object >= 0 && items[top[t].object].tri < 0 && !objects[items[top[t].object].obj].sphere;
+        cursor += mesh_leaf ? (int32_t)mesh_bvhs[objects[items[top[t].object].obj].index]->nodes.size() : 1;
     }
     top_to_global[top.size()] = cursor;
     const uint32_t num_nodes = (uint32_t)cursor, num_tris = (uint32_t)base;
@@ -114,7 +145,7 @@ void Scene::buildBVH() {
     std::vector<int32_t> rec_base(objects.size(), 0);
     std::vector<std::vector<int32_t>> rec_of_tri(meshes.size());
     {
-        std::shared_ptr<BVHAccel> top_ref = sah ? std::make_shared<BVHAccel>(top_objects, 1, BVHAccel::SplitMethod::NAIVE) : bvh_owner_;
+        std::shared_ptr<BVHAccel> top_ref = sah ? std::make_shared<BVHAccel>(ref_objects, 1, BVHAccel::SplitMethod::NAIVE) : bvh_owner_;
         int32_t next = 0;
         for (int32_t obj : top_ref->leafOrder()) {
             rec_base[obj] = next;
@@ -147,7 +178,18 @@ void Scene::buildBVH() {
             write_node(g0, tn.bounds, top_to_global[tn.miss], -1, tn.area);
             continue;
         }
-        const int obj = tn.object;  // index into `objects` = material index
+        const int obj = items[tn.object].obj;  // index into `objects` = material index
+        auto write_triangle = [&](int32_t rec, const Triangle& T, int32_t prim) {
+            float* r = fs->tris.data + 16ull * rec;
+            r[0] = T.v0.x; r[1] = T.v0.y; r[2] = T.v0.z; r[3] = T.area;
+            r[4] = T.e1.x; r[5] = T.e1.y; r[6] = T.e1.z; put_int(r + 7, obj);
+            r[8] = T.e2.x; r[9] = T.e2.y; r[10] = T.e2.z; put_int(r + 11, prim);
+            r[12] = T.normal.x; r[13] = T.normal.y; r[14] = T.normal.z; put_int(r + 15, obj);
+            float* w = fs->tri_v12.data + 8ull * rec;
+            w[0] = T.v1.x; w[1] = T.v1.y; w[2] = T.v1.z; w[3] = 0.f;
+            w[4] = T.v2.x; w[5] = T.v2.y; w[6] = T.v2.z; w[7] = 0.f;
+            fs->prim_of_tri[rec] = prim;
+        };
         if (objects[obj].sphere) {
             const Sphere* sp = spheres[objects[obj].index];
             const int32_t rec = rec_base[obj];
@@ -164,6 +206,13 @@ void Scene::buildBVH() {
         }
         const int k = objects[obj].index;
         const MeshTriangle* mesh = meshes[k];
+        if (items[tn.object].tri >= 0) {  // Sah: a triangle of a small mesh is a leaf of the top level
+            const int ti = items[tn.object].tri;
+            const int32_t rec = rec_base[obj] + rec_of_tri[k][(size_t)ti];
+            write_triangle(rec, mesh->triangles[ti], object_base[obj] + ti);
+            write_node(g0, tn.bounds, top_to_global[tn.miss], rec, tn.area);
+            continue;
+        }
         const std::vector<FlatNode>& mn = mesh_bvhs[k]->nodes;
         // The reference tests the mesh's bounding box (top-level leaf) and then
         // the identical box of the nested root; one test gives the same answer.
@@ -176,16 +225,7 @@ void Scene::buildBVH() {
             int32_t tri = -1;
             if (n.object >= 0) {
                 tri = rec_base[obj] + rec_of_tri[k][(size_t)n.object];
-                const Triangle& T = mesh->triangles[n.object];
-                float* r = fs->tris.data + 16ull * tri;
-                r[0] = T.v0.x; r[1] = T.v0.y; r[2] = T.v0.z; r[3] = T.area;
-                r[4] = T.e1.x; r[5] = T.e1.y; r[6] = T.e1.z; put_int(r + 7, obj);
-                r[8] = T.e2.x; r[9] = T.e2.y; r[10] = T.e2.z; put_int(r + 11, object_base[obj] + n.object);
-                r[12] = T.normal.x; r[13] = T.normal.y; r[14] = T.normal.z; put_int(r + 15, obj);
-                float* w = fs->tri_v12.data + 8ull * tri;
-                w[0] = T.v1.x; w[1] = T.v1.y; w[2] = T.v1.z; w[3] = 0.f;
-                w[4] = T.v2.x; w[5] = T.v2.y; w[6] = T.v2.z; w[7] = 0.f;
-                fs->prim_of_tri[tri] = object_base[obj] + n.object;
+                write_triangle(tri, mesh->triangles[n.object], object_base[obj] + n.object);
             }
             write_node(g0 + (int32_t)i, n.bounds, g0 + n.miss, tri, n.area);
         }

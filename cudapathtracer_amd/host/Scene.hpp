@@ -80,7 +80,7 @@ public:
     // reference's, so every ray with finite reciprocal direction components tests the same triangles and gets the
     // same closest distance and occlusion answer; the triangle records stay in the reference's traversal order (the
     // reference's trees are built once more for that), so of several triangles hit at bitwise equal distance the one
-    // the reference names is named.  Fewer boxes are tested on the way: 9-14 % more rays per second on the bunny and
+    // the reference names is named.  Fewer boxes are tested on the way: 11-16 % more rays per second on the bunny and
     // the 1.0 M-triangle height field.  What is not covered: a ray with a zero direction component whose origin lies
     // exactly on a box plane (0 * inf = NaN in the slab test), where the reference's answer depends on its tree.
     enum class BvhBuild { Reference, Gpu, Sah };
