@@ -880,9 +880,9 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
     } else {
         // Threaded walk with queued triangle tests (kept for trees whose depth exceeds the stack
         // budget, and for comparison): the box walk queues the triangles of the leaves it reaches
-        // (up to kTriQueue per lane) and the tests run in a loop of their own, in
-        // queue order = visit order, so the strict `<` update sees the reference's
-        // sequence.  A lane whose queue is full waits for the flush.
+        // (up to kTriQueue per lane) and the tests run in a loop of their own; among equal
+        // distances the lowest record index wins, which is the reference's first visited.
+        // A lane whose queue is full waits for the flush.
         const float kInf = __builtin_inff();
         const bool finite = fabsf(inv.x) < kInf && fabsf(inv.y) < kInf && fabsf(inv.z) < kInf;
         uint32_t cnt = 0;
@@ -912,7 +912,9 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
                             break;
                         }
                     } else {
-                        if (t < best_t) {
+                        // visit order is record order in the reference's tree; another tree over the same records
+                        // (the host's surface-area build) meets them in another order, so the tie goes by index
+                        if (t < best_t || (t == best_t && tri < best)) {
                             best = tri;
                             best_t = t;
                         }

@@ -169,21 +169,26 @@ def test_culled_traversal(hp, oracle, gpu_ctx, name):
         gpu_ctx.set_traversal(hp.TRAVERSAL_REFERENCE)
 
 
+@pytest.mark.parametrize("sah", [False, True])
 @pytest.mark.parametrize("variant", [0, 1])
-def test_forced_variants(hp, oracle, gpu_ctx, monkeypatch, variant):
+def test_forced_variants(hp, oracle, gpu_ctx, monkeypatch, variant, sah):
     """the variants that are no scene's default: the threaded walk through L1/L2 (0) and from
-    LDS (1), forced through the environment at upload."""
+    LDS (1), forced through the environment at upload; on the reference's tree and on the surface-area tree
+    (whose leaves the walk meets in another order: ties between equal distances still go to the reference's triangle)."""
     from cudapathtracer_amd import scenes
     parts = scenes.heightfield_in_cornell_parts(8)
     w, h, depth, spp = 40, 24, 5, 2
     sc = scenes._assemble(parts, w, h, depth)
+    if sah:
+        sc.buildBVH(sah=True)
     osc = _oracle_scene(oracle, parts, w, h)
     monkeypatch.setenv("HPT_TRACE_VARIANT", str(variant))
     gpu_ctx.upload(sc)
     monkeypatch.delenv("HPT_TRACE_VARIANT")
     assert gpu_ctx.stats()["variant"] == variant
     _same_hits(gpu_ctx, osc, *random_rays(1 << 16, 51))
-    _same_hits(gpu_ctx, osc, *_shadow_batch(1 << 15, 52, down=True))
+    _same_hits(gpu_ctx, osc, *primary_rays(128, 128, scenes.CORNELL_CAM, osc.info()["cam_scale"]))
+    (_same_occlusion if sah else _same_hits)(gpu_ctx, osc, *_shadow_batch(1 << 15, 52, down=True))
     want_acc, _ = osc.render(RNG_PHILOX, TRIG_PORTABLE, depth, spp, fixed=True)
     for mode in (1, 2):
         gpu_ctx.accum_clear()
