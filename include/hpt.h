@@ -75,8 +75,15 @@ typedef struct {
  *   a MISS it is the node's miss link; num_nodes terminates.
  *   Record = 8 floats, 32 bytes:  pMin.xyz, bits(int32 miss link),
  *                                 pMax.xyz, bits(int32 triangle index | -1)
- * tris: in leaf order (= the order the reference traversal meets them; equal-t
- *   ties resolve to the lower index, as the strict `<` of common/BVH.hpp:130 does).
+ *   The array may hold ANY binary tree in this form whose boxes are the unions of the boxes below them and
+ *   whose leaves are the reference's (one triangle or sphere each): a ray with finite reciprocal direction
+ *   components that hits a leaf's box hits every box that encloses it, so the triangles tested -- and with them
+ *   distances, occlusion answers and pictures -- do not depend on the interior nodes.  The host library's
+ *   Scene::BvhBuild::Sah emits such a tree (surface-area splits, fewer boxes tested per ray).  The light table's
+ *   root_node subtrees must be the reference's mesh trees: BVHAccel::getSample descends them.
+ * tris: in leaf order of the REFERENCE's tree (= the order the reference traversal meets them; equal-t
+ *   ties resolve to the lower index, as the strict `<` of common/BVH.hpp:130 does; a tree of another
+ *   shape keeps the records in this order and refers to them by index).
  *   Record = 16 floats, 64 bytes: v0.xyz, area | e1.xyz, bits(material index) |
  *                                 e2.xyz, bits(prim id) | normal.xyz, bits(mesh index)
  *   with e1, e2, normal, area precomputed as common/Triangle.hpp:52-59 does and
