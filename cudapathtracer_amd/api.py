@@ -157,6 +157,7 @@ def _declare(L, H):
     H.hpt_host_material_sample.argtypes = [C.POINTER(hpt_material), C.c_size_t] + [vp] * 4
     H.hpt_host_rng_floats.argtypes = [i32, i32, i32, vp]
     H.hpt_host_set_default_bvh_build.argtypes = [i32]
+    H.hpt_host_default_bvh_build.argtypes = [C.POINTER(C.c_int)]
     H.hpt_host_scene_set_bvh_build.argtypes = [vp, i32]
     H.hpt_host_scene_bvh_build.argtypes = [vp, C.POINTER(C.c_int)]
     L.hpt_set_bvh_build.argtypes = [vp, C.c_int]
@@ -233,17 +234,22 @@ class Scene:
         return s
 
     @staticmethod
-    def CreateNamedScene(name, maxDepth=10, width=0, height=0, models_dir=DEFAULT_MODELS_DIR, bvh_build=BVH_BUILD_HOST):
+    def CreateNamedScene(name, maxDepth=10, width=0, height=0, models_dir=DEFAULT_MODELS_DIR, bvh_build=None):
         """Scene::CreateNamedScene: "cornell" | "bunny" | "glass" | "heightfield:<n>" | "file:<scene file>".
         bvh_build=BVH_BUILD_GPU: the scene is flattened for the device-side build (Scene::default_bvh_build);
         BVH_BUILD_SAH: host build with surface-area splits."""
         H = load_libraries()[1]
         h = C.c_void_p()
-        _ckh(H.hpt_host_set_default_bvh_build(int(bvh_build)))
-        try:
+        if bvh_build is None:   # Scene::default_bvh_build as it stands (the reference's tree unless the process changed it)
             _ckh(H.hpt_host_scene_named(name.encode(), models_dir.encode(), int(width), int(height), int(maxDepth), C.byref(h)))
-        finally:
-            H.hpt_host_set_default_bvh_build(BVH_BUILD_HOST)
+        else:
+            before = C.c_int()
+            _ckh(H.hpt_host_default_bvh_build(C.byref(before)))
+            _ckh(H.hpt_host_set_default_bvh_build(int(bvh_build)))
+            try:
+                _ckh(H.hpt_host_scene_named(name.encode(), models_dir.encode(), int(width), int(height), int(maxDepth), C.byref(h)))
+            finally:
+                H.hpt_host_set_default_bvh_build(before.value)
         w, hh = C.c_int(), C.c_int()
         buf = C.create_string_buffer(256)
         _ckh(H.hpt_host_scene_info(h, C.byref(w), C.byref(hh), buf, 256))

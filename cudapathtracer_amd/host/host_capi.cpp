@@ -287,6 +287,12 @@ int hpt_host_set_default_bvh_build(int build) {
     return 0;
 }
 
+int hpt_host_default_bvh_build(int* build) {
+    if (!build) return fail("null argument");
+    *build = Scene::default_bvh_build == Scene::BvhBuild::Gpu ? HPT_BVH_BUILD_GPU : Scene::default_bvh_build == Scene::BvhBuild::Sah ? HPT_HOST_BVH_BUILD_SAH : HPT_BVH_BUILD_HOST;
+    return 0;
+}
+
 int hpt_host_scene_set_bvh_build(hpt_host_scene* s, int build) {
     if (!s) return fail("scene is null");
     if (!to_bvh_build(build, &s->scene.bvh_build)) return fail("build is none of HPT_BVH_BUILD_HOST, HPT_BVH_BUILD_GPU, HPT_HOST_BVH_BUILD_SAH");

@@ -86,6 +86,7 @@ int hpt_host_render_devices(const hpt_host_scene* s, const int* devices, int num
 /* Scene::default_bvh_build: scenes created from now on flatten for HPT_BVH_BUILD_HOST (default), HPT_BVH_BUILD_GPU
  * (include/hpt.h) or HPT_HOST_BVH_BUILD_SAH; the renderer picks the matching upload. */
 int hpt_host_set_default_bvh_build(int build);
+int hpt_host_default_bvh_build(int* build);
 /* Scene::bvh_build of one scene (takes effect at its next hpt_host_scene_build), and how the scene was last built */
 int hpt_host_scene_set_bvh_build(hpt_host_scene* s, int build);
 int hpt_host_scene_bvh_build(const hpt_host_scene* s, int* build);

@@ -35,6 +35,11 @@ def ref():
 def hp():
     import cudapathtracer_amd
     cudapathtracer_amd.load_libraries()
+    # HPT_TEST_BVH=sah: every scene the tests create without naming a builder gets the surface-area tree (a
+    # diagnostic run of the whole suite on the other tree; tests that compare the tree itself with the reference's
+    # fail by design)
+    if os.environ.get("HPT_TEST_BVH") == "sah":
+        cudapathtracer_amd.api._ckh(cudapathtracer_amd.load_libraries()[1].hpt_host_set_default_bvh_build(cudapathtracer_amd.BVH_BUILD_SAH))
     return cudapathtracer_amd
 
 
