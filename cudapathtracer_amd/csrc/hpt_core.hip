@@ -1054,7 +1054,11 @@ struct hpt_ctx {
     unsigned long long* d_prof = nullptr;  // diagnostic builds only
     float* d_rgb = nullptr;  // staging for hpt_resolve
     // wavefront state
-    uint64_t wf_capacity = 1ull << 24;  // paths per wavefront batch (2 queues x 64 B each: 2 GiB)
+    // paths per wavefront batch: 2 queues x 64 B each = 32 GiB of the 288 GB when a render has that many paths (the
+    // queues are allocated for what a call needs, up to this).  Long batches matter: every bounce of a batch ends in
+    // a workgroup barrier and every batch in a tail of few long paths (bunny 4.6 -> 5.5, 1.0 M-triangle height field
+    // 3.4 -> 4.5 Grays/s from 2^24 to 2^28)
+    uint64_t wf_capacity = 1ull << 28;
     uint64_t wf_allocated = 0;
     float4* d_wf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     uint32_t* d_live = nullptr;  // per-bounce live counters

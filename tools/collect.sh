@@ -11,11 +11,11 @@ cd $GRAFT_REPO_ROOT
 B="timeout -k 10 300 python bench.py"
 # the headline line (with the CPU baseline leg), and the other configurations as side measurements
 $B > $OUT/bench_cornell_mode1.json 2> $OUT/bench.err || exit 1
-$B --mode 2 --steps 4 --warmup 1 --spp-per-step 16 > $OUT/bench_cornell_mode2.json 2>> $OUT/bench.err || exit 1
-# (the streamed mode works in batches of 2^24 paths whatever the step; the single kernel needs a step of many samples
-#  to amortise the end of a launch: 16 spp of 1024^2 are 4 work units per resident wave)
+$B --mode 2 --steps 4 --warmup 1 > $OUT/bench_cornell_mode2.json 2>> $OUT/bench.err || exit 1
+# (steps of many samples: the single kernel needs them to amortise the end of a launch -- 16 spp of 1024^2 are 4 work
+#  units per resident wave -- and the streamed mode to fill its batches of up to 2^28 paths)
 for m in 1 2; do
-  if [ $m = 1 ]; then SB=256; SH=64; else SB=16; SH=4; fi
+  SB=256; SH=64
   $B --scene bunny --mode $m --steps 4 --warmup 1 --spp-per-step $SB > $OUT/bench_bunny_mode$m.json 2>> $OUT/bench.err || exit 1
   $B --scene heightfield:708 --width 2048 --height 2048 --mode $m --steps 3 --warmup 1 --spp-per-step $SH > $OUT/bench_heightfield708_mode$m.json 2>> $OUT/bench.err || exit 1
   $B --no-cpu-baseline --traversal culled --scene bunny --mode $m --steps 3 --warmup 1 --spp-per-step $SB > $OUT/bench_bunny_culled_mode$m.json 2>> $OUT/bench.err || exit 1
@@ -28,8 +28,8 @@ HPT_BENCH_FORCE_DIST=1 $B --no-cpu-baseline --steps 4 --warmup 1 > $OUT/bench_co
 [ "${2:-}" = "bench" ] && { echo collected; exit 0; }
 # counters and kernel traces: the headline kernel, and the streamed kernel on the two large scenes
 bash tools/pmc_scene.sh ${TAG}_cornell_m1 || exit 1
-bash tools/pmc_scene.sh ${TAG}_bunny_m2 --scene bunny --mode 2 --spp-per-step 16 || exit 1
-bash tools/pmc_scene.sh ${TAG}_hf_m2 --scene heightfield:708 --mode 2 --spp-per-step 4 --width 2048 --height 2048 || exit 1
+bash tools/pmc_scene.sh ${TAG}_bunny_m2 --scene bunny --mode 2 --spp-per-step 256 || exit 1
+bash tools/pmc_scene.sh ${TAG}_hf_m2 --scene heightfield:708 --mode 2 --spp-per-step 64 --width 2048 --height 2048 || exit 1
 cd $GRAFT_REPO_ROOT
 if [ -f cudapathtracer_amd/libhpt_count.so ]; then
   HPT_LIBHPT=$PWD/cudapathtracer_amd/libhpt_count.so timeout -k 10 300 python tools/count_tests.py > $OUT/executed_tests.json 2>> $OUT/bench.err || exit 1

@@ -148,7 +148,7 @@ def _run(orc, ctx, cases, first, out, big):
         # how the sample range is rendered: in one call; split over two calls (the sums do not depend on the split);
         # by the entry point that allocates nothing; in streamed batches of a few thousand paths
         how = rs.choice(["one call", "split", "static", "small batches"])
-        ctx.set_wavefront_capacity(int(rs.choice([4096, 20000])) if how == "small batches" else 1 << 24)
+        ctx.set_wavefront_capacity(int(rs.choice([4096, 20000])) if how == "small batches" else 1 << 28)
         if how == "split" and spp > 1:
             ctx.render(mode, block, depth, s0 + 1, spp - 1)
             ctx.render(3 - mode, block, depth, s0, 1)
