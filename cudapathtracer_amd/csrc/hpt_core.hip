@@ -111,8 +111,12 @@ int fail(int code, const char* fmt, ...) {
     } while (0)
 
 // device allocation: HPT_ERR_OUT_OF_MEMORY when the device has no room, HPT_ERR_HIP otherwise
+// HPT_ALLOC_LIMIT=<bytes> (tests): a single allocation beyond it is refused as if the card were full.
 int device_alloc(void** p, size_t bytes, const char* what) {
     *p = nullptr;
+    if (const char* lim = getenv("HPT_ALLOC_LIMIT"))
+        if (bytes > (size_t)strtoull(lim, nullptr, 0))
+            return fail(HPT_ERR_OUT_OF_MEMORY, "out of device memory allocating %zu bytes for %s (HPT_ALLOC_LIMIT)", bytes, what);
     const hipError_t e = hipMalloc(p, bytes ? bytes : 1);
     if (e == hipSuccess) return HPT_OK;
     (void)hipGetLastError();  // the failed allocation must not poison the next hipGetLastError()
@@ -1644,7 +1648,7 @@ int render_launch(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sam
         const int wblock = block > 256 ? 256 : block;
         const uint64_t total = lanes * (uint64_t)sample_count;
         const uint64_t cap_limit = fixed ? fixed->wf_paths : ctx->wf_capacity;
-        const uint64_t cap = cap_limit < total ? cap_limit : ((total + 63ull) & ~63ull);
+        uint64_t cap = cap_limit < total ? cap_limit : ((total + 63ull) & ~63ull);
         // one queue segment per workgroup; exactly the workgroups that are resident at once
         int per_cu = 0;
         // scenes read through two-child records run the wave scheduler (HPT_WF_SCHEDULER=0: the plain loop, for A/B runs)
@@ -1662,22 +1666,31 @@ int render_launch(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sam
             }
         })
         if (per_cu < 1) return fail(HPT_ERR_INVALID_ARGUMENT, "the wavefront kernel does not fit a compute unit with %u bytes of LDS", lds_bytes(S, wblock));
-        const uint64_t cap_groups = (cap + 63ull) >> 6;
-        uint32_t segments = (uint32_t)std::min<uint64_t>((uint64_t)per_cu * (uint64_t)ctx->num_cus, cap_groups);
-        if (fixed) segments = (uint32_t)std::min<uint64_t>(segments, fixed->live_slots);
-        uint32_t seg = (uint32_t)((cap_groups + segments - 1ull) / segments) * 64u;  // records per segment
+        uint32_t segments = 0, seg = 0;
         float4* const* wf = ctx->d_wf;
         uint32_t* live = nullptr;
-        if (fixed) {
-            // fixed buffers: whole segments must fit (rounding each segment up to 64 records can
-            // take the batch past the buffer: then the segments shrink and the batch with them)
-            if ((uint64_t)seg * segments > fixed->wf_paths) seg = (uint32_t)(fixed->wf_paths / segments) & ~63u;
-            if (seg == 0) return fail(HPT_ERR_TOO_LARGE, "the fixed path queues (%llu records) are too small for %u segments", (unsigned long long)fixed->wf_paths, segments);
-            wf = fixed->wf;
-            live = fixed->live;
-        } else {
-            if (int rc = ensure_wavefront(ctx, (uint64_t)seg * segments, segments)) return rc;
-            live = ctx->d_live;
+        for (;;) {
+            const uint64_t cap_groups = (cap + 63ull) >> 6;
+            segments = (uint32_t)std::min<uint64_t>((uint64_t)per_cu * (uint64_t)ctx->num_cus, cap_groups);
+            if (fixed) segments = (uint32_t)std::min<uint64_t>(segments, fixed->live_slots);
+            seg = (uint32_t)((cap_groups + segments - 1ull) / segments) * 64u;  // records per segment
+            if (fixed) {
+                // fixed buffers: whole segments must fit (rounding each segment up to 64 records can
+                // take the batch past the buffer: then the segments shrink and the batch with them)
+                if ((uint64_t)seg * segments > fixed->wf_paths) seg = (uint32_t)(fixed->wf_paths / segments) & ~63u;
+                if (seg == 0) return fail(HPT_ERR_TOO_LARGE, "the fixed path queues (%llu records) are too small for %u segments", (unsigned long long)fixed->wf_paths, segments);
+                wf = fixed->wf;
+                live = fixed->live;
+                break;
+            }
+            const int rc = ensure_wavefront(ctx, (uint64_t)seg * segments, segments);
+            if (rc == HPT_OK) {
+                live = ctx->d_live;
+                break;
+            }
+            // the queues of a long batch can be tens of GiB: if the card cannot give them, trace shorter batches
+            if (rc != HPT_ERR_OUT_OF_MEMORY || cap <= (1ull << 16)) return rc;
+            cap = ((cap >> 1) + 63ull) & ~63ull;
         }
         const uint64_t batch = std::min<uint64_t>(cap, (uint64_t)seg * segments);  // paths per generate + bounces pair
         WfQueue q[2] = {{wf[0], wf[1], wf[2], wf[3]}, {wf[4], wf[5], wf[6], wf[7]}};

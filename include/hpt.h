@@ -148,7 +148,8 @@ int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* scene);
 /* Options that have no counterpart in the reference CLI.
  *   seed: word 2 of the Philox counter (default 0)
  *   wavefront_capacity: paths in flight per streamed batch (default 1<<28; the two queues take 128 bytes per path of
- *   a batch and are allocated for what a call needs: 32 GiB for a call of 2^28 paths or more)   */
+ *   a batch and are allocated for what a call needs: 32 GiB for a call of 2^28 paths or more; when the card cannot
+ *   give that much the batch is halved until the queues fit)   */
 int hpt_set_seed(hpt_ctx* ctx, uint32_t seed);
 int hpt_set_wavefront_capacity(hpt_ctx* ctx, uint64_t paths);
 

@@ -302,9 +302,44 @@ def test_wavefront_small_capacity_batches(hp, oracle, gpu_ctx):
         gpu_ctx.render(2, 256, depth, 0, spp)
         got = gpu_ctx.resolve(spp)
     finally:
-        gpu_ctx.set_wavefront_capacity(1 << 24)
+        gpu_ctx.set_wavefront_capacity(1 << 28)
     want_acc, _ = oracle.cornell(w, h).render(RNG_PHILOX, TRIG_PORTABLE, depth, spp, fixed=True)
     assert np.array_equal(got.view(np.int32), oracle.resolve(want_acc, spp).view(np.int32))
+
+
+def test_wavefront_queues_shrink_when_the_card_is_full(hp, monkeypatch):
+    """The streamed mode sizes its two path queues for the call (up to 2^28 paths, 32 GiB); when the card cannot give
+    that much it halves the batch until the queues fit, and the sums are the same.  Card fullness is simulated with
+    HPT_ALLOC_LIMIT (a single allocation beyond it is refused as out of memory)."""
+    w, h, depth, spp = 512, 512, 6, 8                      # 2 M paths: 32 MiB per queue plane
+    sc = hp.Scene.CreateBuiltinScene(hp.Scene.CornellBox, depth, w, h)
+    ctx = hp.Context(0)
+    try:
+        ctx.upload(sc)
+        ctx.accum_clear()
+        ctx.render(1, 256, depth, 0, spp)
+        want = ctx.accum_download()
+        ctx.close()
+        ctx = hp.Context(0)
+        ctx.upload(sc)
+        monkeypatch.setenv("HPT_ALLOC_LIMIT", str(5 << 20))   # 5 MiB: batches of 2^18 paths at most
+        ctx.stats_reset()
+        ctx.accum_clear()
+        ctx.render(2, 256, depth, 0, spp)
+        assert np.array_equal(ctx.accum_download(), want)
+        assert ctx.stats()["launches"] >= 2 * 8            # generate + bounces per batch, at least 8 batches
+        monkeypatch.setenv("HPT_ALLOC_LIMIT", "4096")       # nothing fits: the error comes out
+        ctx.set_wavefront_capacity(1 << 24)
+        ctx2 = hp.Context(0)
+        try:
+            with pytest.raises(hp.HptError, match="out of device memory"):
+                ctx2.upload(sc)
+        finally:
+            monkeypatch.delenv("HPT_ALLOC_LIMIT")
+            ctx2.close()
+    finally:
+        monkeypatch.delenv("HPT_ALLOC_LIMIT", raising=False)
+        ctx.close()
 
 
 def test_error_paths(hp, gpu_ctx):
