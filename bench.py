@@ -117,8 +117,7 @@ def main():
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--depth", type=int, default=20)
     ap.add_argument("--mode", type=int, default=1, help="1 single kernel, 2 streamed (wavefront)")
-    ap.add_argument("--block", type=int, default=256, help="workgroup size (the CLI's <threads>); 64 = one wave per "
-                    "workgroup schedules best (12.1 vs 11.0 Grays/s at 256)")
+    ap.add_argument("--block", type=int, default=256, help="workgroup size (the CLI's <threads>; 256 is the benchmark configuration's)")
     ap.add_argument("--cpu-spp", type=int, default=32, help="samples of the CPU baseline leg (0 = skip); 32 = 14 s of the GPU box's 16 host threads on the Cornell box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traversal", default="reference", choices=["reference", "culled"],
