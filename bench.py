@@ -4,12 +4,19 @@
     python bench.py --gpus N --steps K --warmup W
 
 A *step* is one pass of the hot path over one batch: --spp-per-step samples of
-every pixel of the 1k x 1k image (default 64 -> 67 M camera paths, about
-780 M rays; the 4096-spp configuration is 64 such steps).  With N > 1 (one process per GPU, launched by torch.distributed.run)
+every pixel of the 1k x 1k image (default 1024 -> 1.07 G camera paths, about
+12.5 G rays, four kernel launches; the 4096-spp configuration is four such steps).
+With N > 1 (one process per GPU, launched by torch.distributed.run)
 every rank traces its own, disjoint sample ranges (weak scaling: per-GPU work
 per step is fixed) and the int64 accumulation buffers are summed onto rank 0
 with ONE RCCL reduce at the end of the timed region, which also contains the
 final fixed-point -> float resolve on rank 0.
+
+--scaling strong: the job is --total-spp samples per pixel (default 4096: the
+reference README's picture), split evenly over the steps and, inside a step,
+over the ranks; same timed region, "scaling": "strong".  The default (weak) line
+carries the same measurement as a side leg, `strong_config`: the 4096-spp Cornell
+render sharded over the N ranks + one reduce, timed after the weak region.
 
 Rank 0 prints one JSON line.  `value` = Mrays/s over the whole job, rays
 counted by device counters (ray = one BVH query, closest-hit or shadow).
@@ -20,6 +27,11 @@ import json
 import os
 import sys
 import time
+
+# Before anything can initialise the GPU runtime (ROCr reads its settings once, when HSA starts: `import torch`
+# may already do that): the host driver of this pool only supports dmabuf IPC, and RCCL's cross-process buffer
+# sharing fails with `hipIpcGetMemHandle: invalid argument` when the legacy IPC mode is left on.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -107,12 +119,32 @@ def load_json(name):
         return {}
 
 
+def kernel_name(mode, variant, extended_hint=""):
+    """The kernel a render of this mode launches for a scene of this traversal variant (hpt_core.hip: the
+    two-child-record walks through L1/L2, variants 5 and 7, run under the wave scheduler unless it is switched off)."""
+    def off(name):
+        return os.environ.get(name, "") not in ("", "1")
+    scheduler = variant in (5, 7) and not off("HPT_SCHEDULER") and not (mode == 2 and off("HPT_WF_SCHEDULER"))
+    mask = os.environ.get("HPT_MEGA_SCHEDULER_VARIANTS" if mode == 1 else "HPT_WF_SCHEDULER_VARIANTS")
+    if mask is not None:
+        scheduler = variant in (2, 3, 5, 6, 7) and bool((int(mask, 0) >> variant) & 1) and not off("HPT_SCHEDULER")
+    if mode == 1:
+        return "k_render_mega_sm" if scheduler else "k_render_mega"
+    return ("k_wf_bounces_sm" if scheduler else "k_wf_bounces") + " (+ k_wf_generate)"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--spp-per-step", type=int, default=256)
+    ap.add_argument("--spp-per-step", type=int, default=1024,
+                    help="samples per pixel per step and GPU (weak scaling); 1024 = four launches of 2^28 paths, about 0.4 s on the Cornell box")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): every GPU traces --spp-per-step samples per step; strong: --total-spp samples per pixel "
+                         "are split over the steps and, inside a step, over the GPUs")
+    ap.add_argument("--total-spp", type=int, default=4096, help="samples per pixel of the whole job with --scaling strong, and of the strong_config leg")
+    ap.add_argument("--no-strong-leg", action="store_true", help="skip the strong_config side leg (the --total-spp render sharded over the ranks)")
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--depth", type=int, default=20)
@@ -123,9 +155,9 @@ def main():
     ap.add_argument("--traversal", default="reference", choices=["reference", "culled"],
                     help="reference = the reference's box/triangle tests exactly (the parity path); culled = near-first "
                          "order with distance culling for scenes of more than 64 triangles (opt-in, not bit-guaranteed)")
-    ap.add_argument("--bvh-build", default="host", choices=["host", "gpu", "sah"],
-                    help="host: the reference's tree (default); gpu: traversal records built on the device at upload; "
-                         "sah: host build with surface-area splits (side measurements; scenes other than cornell)")
+    ap.add_argument("--bvh-build", default="default", choices=["default", "host", "gpu", "sah"],
+                    help="default: what the host library builds by itself; host: the reference's tree; gpu: traversal records built on the "
+                         "device at upload; sah: host build with surface-area splits (scenes other than cornell)")
     ap.add_argument("--scene", default="cornell", help="cornell (the headline workload) | bunny | heightfield:<n> "
                     "(side measurements of the other configurations; they never change the default line)")
     args = ap.parse_args()
@@ -141,6 +173,7 @@ def main():
     import torch
     import torch.distributed as dist
     import cudapathtracer_amd as hp
+    from cudapathtracer_amd.sharding import reduce_accum, sample_range
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (there is no CPU fallback)")
@@ -159,8 +192,6 @@ def main():
         sys.stdout.flush()
         json_fd = os.dup(1)
         os.dup2(2, 1)
-        # the host driver of this pool only supports dmabuf IPC; RCCL's buffer sharing needs it switched on
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
@@ -169,8 +200,6 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-
-    from cudapathtracer_amd.sharding import reduce_accum
 
     def reduce_sum(t):
         reduce_accum(t, dist, 0)
@@ -184,6 +213,9 @@ def main():
             t.copy_(h)
 
     W, H, depth, spp_step = args.width, args.height, args.depth, args.spp_per_step
+    strong = args.scaling == "strong"
+    if strong and args.total_spp < args.steps * world:
+        sys.exit("--scaling strong: --total-spp %d gives some rank of some step no sample (%d steps x %d GPUs)" % (args.total_spp, args.steps, world))
     if args.scene == "cornell":
         scene = hp.Scene.CreateBuiltinScene(hp.Scene.CornellBox, depth, W, H)
     else:
@@ -193,6 +225,9 @@ def main():
             scene.buildBVH(gpu=True)
         elif args.bvh_build == "sah":
             scene.buildBVH(sah=True)
+        elif args.bvh_build == "host":
+            scene.buildBVH(gpu=False)
+    bvh_built = {hp.BVH_BUILD_HOST: "host", hp.BVH_BUILD_GPU: "gpu", hp.BVH_BUILD_SAH: "sah"}.get(scene.bvh_build, "host")
     ctx = hp.Context(dev_index)
     if args.traversal == "culled":
         ctx.set_traversal(1)
@@ -209,45 +244,105 @@ def main():
         ctx.synchronize()
         torch.cuda.synchronize()
 
-    # sample ranges: step k of rank r traces samples [(k*world + r)*spp_step, +spp_step)
-    total_spp = args.steps * world * spp_step
-    warm_base = total_spp  # warm-up samples lie outside the timed range
+    # what every rank traces in step k: (first sample, number of samples)
+    #   weak:   step k of rank r = samples [(k*world + r)*spp_step, +spp_step)
+    #   strong: the job's total_spp samples split evenly over the steps, a step's share evenly over the ranks
+    def step_range(k, total=None):
+        if total is None:
+            return (k * world + rank) * spp_step, spp_step
+        b0, n0 = sample_range(total, k, args.steps)
+        b1, n1 = sample_range(n0, rank, world)
+        return b0 + b1, n1
+
+    total_spp = args.total_spp if strong else args.steps * world * spp_step
+    warm_base = max(total_spp, args.total_spp)  # warm-up samples lie outside the timed ranges
+    warm_spp = spp_step if not strong else max(1, args.total_spp // (args.steps * world))
     if use_dist:  # warm up the communicator as well
         reduce_sum(accum)
     for k in range(args.warmup):
-        ctx.render(args.mode, args.block, depth, warm_base + (k * world + rank) * spp_step, spp_step, accum=accum, stream=stream)
+        ctx.render(args.mode, args.block, depth, warm_base + (k * world + rank) * warm_spp, warm_spp, accum=accum, stream=stream)
     barrier()
     accum.zero_()
     ctx.stats_reset()
 
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        ctx.render(args.mode, args.block, depth, (k * world + rank) * spp_step, spp_step, accum=accum, stream=stream)
-    if use_dist:
-        reduce_sum(accum)
-    if rank == 0:
-        ctx.resolve_dev(total_spp, rgb, accum=accum, stream=stream)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    def timed_region(total):
+        """The K steps, the reduce and the resolve between two barriers; returns (seconds, reduce ms of this rank, wall-clock start, stop)."""
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        wall0 = time.time()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            b, n = step_range(k, total)
+            if n:
+                ctx.render(args.mode, args.block, depth, b, n, accum=accum, stream=stream)
+        reduce_ms = None
+        if use_dist:
+            # the collective, seen from this rank's stream: from the end of its own renders to the reduced buffer
+            ev0.record(stream)
+            reduce_sum(accum)
+            ev1.record(stream)
+        if rank == 0:
+            ctx.resolve_dev(total if total is not None else total_spp, rgb, accum=accum, stream=stream)
+        barrier()
+        dt = time.perf_counter() - t0
+        wall1 = time.time()
+        if use_dist:
+            reduce_ms = float(ev0.elapsed_time(ev1))
+        return dt, reduce_ms, wall0, wall1
+
+    elapsed, reduce_ms, wall0, wall1 = timed_region(args.total_spp if strong else None)
 
     st = ctx.stats()
     rays = st["closest_queries"] + st["shadow_queries"]
-    agg = torch.tensor([float(rays), float(st["paths"]), float(st["closest_queries"])], dtype=torch.float64, device=dev)
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if use_dist:
-        all_reduce(agg, dist.ReduceOp.SUM)
-        all_reduce(tmax, dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
-    total_rays, total_paths, total_closest = (float(v) for v in agg.tolist())
 
+    def whole_job(st_, dt):
+        """(rays, paths, closest queries) summed and the time maximised over the ranks."""
+        agg = torch.tensor([float(st_["closest_queries"] + st_["shadow_queries"]), float(st_["paths"]), float(st_["closest_queries"])],
+                           dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if use_dist:
+            all_reduce(agg, dist.ReduceOp.SUM)
+            all_reduce(tmax, dist.ReduceOp.MAX)
+        return [float(v) for v in agg.tolist()] + [float(tmax.item())]
+
+    total_rays, total_paths, total_closest, elapsed = whole_job(st, elapsed)
+
+    # who took part: every rank's device, as torch.distributed saw the job
+    me = {"rank": rank, "device_index": dev_index, "device_name": torch.cuda.get_device_name(dev_index),
+          "pci_bus_id": getattr(torch.cuda.get_device_properties(dev_index), "pci_bus_id", None), "reduce_ms": reduce_ms}
+    ranks = [me]
+    if use_dist:
+        ranks = [None] * dist.get_world_size()
+        dist.all_gather_object(ranks, me)
+
+    img_ok = True
     if rank == 0:
         img = rgb.view(-1, 3)
         mean = [float(v) for v in img.mean(dim=0).tolist()]
-        ok = bool(torch.isfinite(img).all().item()) and mean[0] > 0.02 and int(total_paths) == W * H * total_spp
-        if not ok:
-            sys.exit("bench.py: implausible render (mean %r, paths %d, expected %d)" % (mean, int(total_paths), W * H * total_spp))
+        img_ok = bool(torch.isfinite(img).all().item()) and mean[0] > 0.02 and int(total_paths) == W * H * total_spp
+        if not img_ok:
+            sys.stderr.write("bench.py: implausible render (mean %r, paths %d, expected %d)\n" % (mean, int(total_paths), W * H * total_spp))
 
+    # Side leg (default weak line only): BASELINE's sharded configuration as it is stated -- --total-spp (4096) samples per
+    # pixel of the benchmarked scene split over the ranks, ONE reduce, resolve on rank 0 -- timed like the region above.
+    strong_leg = None
+    if not strong and not args.no_strong_leg and args.total_spp >= args.steps * world:
+        accum.zero_()
+        ctx.stats_reset()
+        s_dt, s_reduce_ms, s_w0, s_w1 = timed_region(args.total_spp)
+        s_st = ctx.stats()
+        s_rays, s_paths, _, s_dt = whole_job(s_st, s_dt)
+        strong_leg = {"scaling": "strong", "total_spp": args.total_spp, "n_gpus": world, "seconds": s_dt,
+                      "value": s_rays / s_dt / 1e6, "unit": "Mrays/s", "spp_per_sec": args.total_spp / s_dt,
+                      "reduce_ms_rank0": s_reduce_ms, "paths": int(s_paths), "paths_expected": W * H * args.total_spp,
+                      "wall_clock_start": s_w0, "wall_clock_stop": s_w1,
+                      "note": "the same job for every N: %d spp of %s %dx%d depth %d sharded over the ranks, one reduce, resolve; "
+                              "time = max over ranks between two barriers" % (args.total_spp, args.scene, W, H, depth)}
+        if rank == 0 and int(s_paths) != W * H * args.total_spp:
+            img_ok = False
+            sys.stderr.write("bench.py: the strong leg traced %d paths, expected %d\n" % (int(s_paths), W * H * args.total_spp))
+
+    if rank == 0 and img_ok:
         cpu, per_ray = None, None
         if world == 1 and not args.no_cpu_baseline and args.cpu_spp > 0:
             cpu, per_ray = cpu_baseline(args.scene, W, H, depth, args.cpu_spp)
@@ -255,7 +350,8 @@ def main():
         launches = max(1, st["launches"])
         if args.mode == 2:
             launches //= 2                                # a streamed batch = generate + bounce loop: priced as one unit
-        kernel_ms = st["kernel_ms"] / max(1, launches)    # rank 0's average launch, HIP events on its stream
+        launches = max(1, launches)
+        kernel_ms = st["kernel_ms"] / launches            # rank 0's average launch, HIP events on its stream
         rays_per_launch = rays / launches
         closest_per_launch = st["closest_queries"] / launches
         # where the traversal's records live decides the bound: LDS (staged per workgroup) -> VALU issue;
@@ -263,21 +359,27 @@ def main():
         variant = st["variant"]
         desc = scene.describe()
         record_bytes = 64 * (desc.num_tris + desc.num_nodes // 2)    # triangle records + two-child records
-        # (the 190 MB of the 1.0 M-triangle scene do not fit the L2s, but what crosses the fabric -- `traffic`,
-        # 2.3 TB/s -- is under a third of the HBM peak and half of the lookups still hit L2: the L2 request
+        # (the 190 MB of the 1.0 M-triangle scene do not fit the L2s, but what crosses the fabric -- `traffic` --
+        # stays under half of the HBM peak and half of the lookups still hit L2: the L2 request
         # path is the nearer bound there too; hbm_traffic_GBps / hbm_traffic_frac state the HBM side)
         bound = "valu" if variant in (1, 2, 3, 6) else "l2"
-        key = "%s_mode%d_%dx%d_d%d_spp%d" % (args.scene, args.mode, W, H, depth, spp_step) + ("_culled" if args.traversal == "culled" else "")
+        # the PMC files are keyed by the samples ONE launch traces (a launch is at most 2^28 camera paths)
+        tiles = ((W + 7) // 8) * ((H + 7) // 8)
+        per_rank_step = spp_step if not strong else max(1, args.total_spp // (args.steps * world))
+        spp_launch = max(1, min(per_rank_step, (1 << 22) // tiles))
+        key = "%s_mode%d_%dx%d_d%d_spp%d" % (args.scene, args.mode, W, H, depth, spp_launch) + ("_culled" if args.traversal == "culled" else "") \
+            + ("" if bvh_built == "host" or args.scene == "cornell" else "_" + bvh_built)
         pm = load_json("hbm_traffic.json").get(key, {})
         ex = load_json("executed_tests.json").get("%s_%dx%d_d%d_mode%d" % (args.scene, W, H, depth, args.mode)
-                                                  + ("_culled" if args.traversal == "culled" else ""), {})
+                                                  + ("_culled" if args.traversal == "culled" else "")
+                                                  + ("" if bvh_built == "host" or args.scene == "cornell" else "_" + bvh_built), {})
         roof = {"bound": bound, "achieved": None, "peak": None, "unit": None, "frac": None,
                 "traffic": pm.get("hbm_bytes_per_launch"),
-                "kernel": "k_render_mega" if args.mode == 1 else "k_wf_bounces (+ k_wf_generate)",
-                "kernel_ms": kernel_ms, "launches": launches, "traversal_variant": variant,
+                "kernel": kernel_name(args.mode, variant),
+                "kernel_ms": kernel_ms, "launches": launches, "spp_per_launch": spp_launch, "traversal_variant": variant,
                 "scene_record_bytes": record_bytes,
                 "valu_active_lane_fraction": pm.get("valu_active_lane_fraction"),   # PMC, same source file as `traffic`
-                "l2_hit_rate": pm.get("l2_hit_rate"), "counter_source": pm.get("source"),
+                "l2_hit_rate": pm.get("l2_hit_rate"), "counter_source": pm.get("source"), "counter_key": key,
                 "records_fit_one_xcd_l2": record_bytes <= L2_BYTES_PER_XCD}
         if roof["traffic"]:
             roof["hbm_traffic_GBps"] = roof["traffic"] / (kernel_ms * 1e-3) / 1e9
@@ -314,26 +416,37 @@ def main():
                     "record_GBps": ebytes / (kernel_ms * 1e-3) / 1e9,
                     "note": "tests the kernel executes (diagnostic counting build, profiles/executed_tests.json); a fetched record "
                             "holds two boxes (32 bytes per box test)"}
+        scene_text = "Cornell" if args.scene == "cornell" else args.scene
         out = {
-            "metric": "Mrays/sec + spp/sec (whole node), Cornell 1k^2 depth 20",
+            "metric": "Mrays/sec + spp/sec (whole node), %s %s depth %d" % (
+                scene_text, "1k^2" if (W, H) == (1024, 1024) else "%dx%d" % (W, H), depth),
             "value": total_rays / elapsed / 1e6,
             "unit": "Mrays/s",
             "spp_per_sec": total_spp / elapsed,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32 (+f64 in the triangle test, int64 accumulators)",
             "data": "synthetic: %s, Philox-keyed samples" % ("built-in Cornell box (models/cornellbox)" if args.scene == "cornell" else args.scene),
-            "config": {"workload": "%s %dx%d, depth %d, mode %d (%s), block %d, %d spp per step per GPU; "
-                                   "%d spp in the timed region" % (
-                                       "Cornell box" if args.scene == "cornell" else args.scene, W, H, depth, args.mode, "single kernel" if args.mode == 1 else "streamed", args.block,
-                                       spp_step, total_spp),
+            "config": {"workload": ("%s %dx%d, depth %d, mode %d (%s), block %d, " % (
+                                        "Cornell box" if args.scene == "cornell" else args.scene, W, H, depth, args.mode,
+                                        "single kernel" if args.mode == 1 else "streamed", args.block))
+                                   + ("%d spp per step per GPU (%d launches of %d spp); %d spp in the timed region" % (
+                                        spp_step, -(-spp_step // spp_launch), spp_launch, total_spp) if not strong else
+                                      "%d spp in all, split over %d steps and %d GPUs" % (total_spp, args.steps, world)),
                        "rays_per_path": total_rays / total_paths,
                        "traversal": args.traversal,
-                       "bvh_build": args.bvh_build if args.scene != "cornell" else "host",
+                       "bvh_build": bvh_built if args.scene != "cornell" else "host",
                        "gpu_bvh_build_ms": ctx.build_info()["gpu_build_ms"] or None,
                        "parallelism": ("spp-sharded x%d, one %s reduce" % (world, "RCCL" if backend == "nccl" else backend)) if use_dist else "1 GPU",
-                       "collective_backend": (dist.get_backend() if use_dist else None)},
+                       "collective_backend": (dist.get_backend() if use_dist else None),
+                       # what torch.distributed itself reports (not the flag, not the environment)
+                       "world_size": (dist.get_world_size() if use_dist else 1),
+                       "ranks": ranks,
+                       "reduce_ms": reduce_ms,
+                       "reduce_bytes": (accum.numel() * 8 if use_dist else 0),
+                       "wall_clock_start": wall0, "wall_clock_stop": wall1},
+            "strong_config": strong_leg,
             "roofline": roof,
             "cpu_baseline": cpu,
         }
@@ -343,6 +456,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+    if not img_ok:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -129,6 +129,8 @@ def _declare(L, H):
     L.hpt_stats_reset.argtypes = [vp]
     L.hpt_accum_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.hpt_accum_reduce.argtypes = [C.POINTER(vp), i32, i32]
+    L.hpt_accum_reduce_prepare.argtypes = [C.POINTER(vp), i32]
+    L.hpt_accum_reduce_info.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
     L.hpt_synchronize.argtypes = [vp]
     L.hpt_accum_download.argtypes = [vp, vp, vp]
     H.hpt_host_last_error.restype = C.c_char_p
@@ -386,13 +388,14 @@ class Scene:
     def render_cpp(self, spp, max_depth, num_threads=256, mode=SingleKernel, device=0, iterative=False, devices=None):
         """Render through the C++ HipRenderer class: PrepareRender/Render/FinishRender, or
         (iterative) PrepareRender, PathTrace(scene, iter) spp times, FinishRender.
-        devices: list of GPU indices to shard the samples over (HipRenderer::devices)."""
+        devices: list of GPU indices to shard the samples over (HipRenderer::devices); with devices, iterative=2 is
+        Render() of the first spp // 2 samples followed by PathTrace for the rest."""
         rgb = np.zeros((self.width * self.height, 3), np.float32)
         st = hpt_stats()
         if devices is not None:
             arr = (C.c_int * len(devices))(*devices)
             _ckh(self._H.hpt_host_render_devices(self._h, arr, len(devices), spp, max_depth, num_threads, mode,
-                                                 1 if iterative else 0, rgb.ctypes.data, C.byref(st)))
+                                                 int(iterative), rgb.ctypes.data, C.byref(st)))
             return rgb, st.as_dict()
         fn = self._H.hpt_host_render_iterative if iterative else self._H.hpt_host_render
         _ckh(fn(self._h, device, spp, max_depth, num_threads, mode, rgb.ctypes.data, C.byref(st)))
@@ -650,6 +653,20 @@ def accum_reduce(contexts, root=0):
     driving several GPUs; RCCL between distinct devices)."""
     arr = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
     _ck(load_libraries()[0].hpt_accum_reduce(arr, len(contexts), int(root)))
+
+
+def accum_reduce_prepare(contexts):
+    """hpt_accum_reduce_prepare: create the RCCL communicators a reduce over these contexts will use (kept
+    and reused; nothing to do when they share one GPU)."""
+    arr = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
+    _ck(load_libraries()[0].hpt_accum_reduce_prepare(arr, len(contexts)))
+
+
+def accum_reduce_info():
+    """hpt_accum_reduce_info: (communicator sets created by this process so far, host ms of the last reduce)."""
+    n, ms = C.c_uint64(), C.c_double()
+    _ck(load_libraries()[0].hpt_accum_reduce_info(C.byref(n), C.byref(ms)))
+    return int(n.value), float(ms.value)
 
 
 def device_count():

@@ -19,6 +19,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -81,6 +82,11 @@ int fail(int code, const char* fmt, ...);
 // device address of `scratch` on `device` (which must be current); looked up once per device
 std::mutex g_scratch_mutex;
 unsigned char* g_scratch_ptr[kMaxDevices] = {};
+// All hpt_render_static calls on a GPU share its scratch: each call makes its stream wait for the event the
+// previous call on that GPU recorded, then records it again.  One event per GPU, created here with the GPU's
+// first context and kept like the scratch itself, so the call creates nothing.
+hipEvent_t g_scratch_event[kMaxDevices] = {};
+bool g_scratch_event_recorded[kMaxDevices] = {};
 int scratch_of(int device, unsigned char** out) {
     if (device < 0 || device >= kMaxDevices) return fail(HPT_ERR_INVALID_ARGUMENT, "device %d: the static scratch serves devices 0..%d", device, kMaxDevices - 1);
     std::lock_guard<std::mutex> lock(g_scratch_mutex);
@@ -88,6 +94,10 @@ int scratch_of(int device, unsigned char** out) {
         void* p = nullptr;
         const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
         if (e != hipSuccess || !p) return fail(HPT_ERR_HIP, "hipGetSymbolAddress(scratch) on device %d failed: %s", device, hipGetErrorString(e));
+        hipEvent_t ev = nullptr;
+        const hipError_t e2 = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e2 != hipSuccess) return fail(HPT_ERR_HIP, "hipEventCreateWithFlags on device %d failed: %s", device, hipGetErrorString(e2));
+        g_scratch_event[device] = ev;
         g_scratch_ptr[device] = static_cast<unsigned char*>(p);
     }
     *out = g_scratch_ptr[device];
@@ -1540,6 +1550,46 @@ int load_rccl() {
         if (r_ != 0) return fail(HPT_ERR_HIP, "%s failed: %s", #expr, g_rccl.GetErrorString(r_));             \
     } while (0)
 
+// Communicators are kept for the life of the process's contexts: one set per ordered list of devices,
+// created by the first reduce over that list (or ahead of it by hpt_accum_reduce_prepare) and destroyed
+// when the last context of the process is destroyed.  Creating a communicator costs tens to hundreds of
+// milliseconds (bootstrap, topology search, buffer registration), a reduce of 25 MB over xGMI a fraction
+// of one: a reduce that created its communicator every time would be communicator creation and little else.
+struct CommSet {
+    std::vector<int> devs;
+    std::vector<void*> comms;
+};
+std::mutex g_comm_mutex;
+std::vector<CommSet> g_comm_sets;
+unsigned long long g_comm_created = 0;  // communicator sets created since the process started
+int g_live_contexts = 0;
+double g_last_reduce_ms = 0.0;
+
+// the set for `devs`, created if the process has none yet (g_comm_mutex held by the caller)
+int comm_set_for(const std::vector<int>& devs, const CommSet** out) {
+    for (const CommSet& s : g_comm_sets)
+        if (s.devs == devs) {
+            *out = &s;
+            return HPT_OK;
+        }
+    if (int rc = load_rccl()) return rc;
+    CommSet s;
+    s.devs = devs;
+    s.comms.assign(devs.size(), nullptr);
+    RCCL_TRY(g_rccl.CommInitAll(s.comms.data(), (int)devs.size(), devs.data()));
+    ++g_comm_created;
+    g_comm_sets.push_back(std::move(s));
+    *out = &g_comm_sets.back();
+    return HPT_OK;
+}
+
+void comm_sets_destroy_all() {
+    for (CommSet& s : g_comm_sets)
+        for (void* c : s.comms)
+            if (c) (void)g_rccl.CommDestroy(c);
+    g_comm_sets.clear();
+}
+
 // Buffers a render needs beyond its inputs and outputs.  nullptr for `fixed` in render_launch =
 // the context's own (the wavefront queues grow on demand); otherwise exactly these are used and
 // nothing is allocated.
@@ -1768,6 +1818,10 @@ int hpt_context_create(int device, hpt_ctx** out) {
     (void)hipMalloc((void**)&ctx->d_prof, 3 * kProfSections * sizeof(unsigned long long));
     (void)hipMemset(ctx->d_prof, 0, 3 * kProfSections * sizeof(unsigned long long));
 #endif
+    {
+        std::lock_guard<std::mutex> lock(g_comm_mutex);
+        ++g_live_contexts;
+    }
     *out = ctx;
     return HPT_OK;
 }
@@ -1783,6 +1837,11 @@ int hpt_context_destroy(hpt_ctx* ctx) {
     (void)hipFree(ctx->d_stats);
     (void)hipFree(ctx->d_unit_counter);
     delete ctx;
+    {
+        // the communicators of hpt_accum_reduce go with the process's last context
+        std::lock_guard<std::mutex> lock(g_comm_mutex);
+        if (--g_live_contexts == 0) comm_sets_destroy_all();
+    }
     return HPT_OK;
 }
 
@@ -2119,7 +2178,7 @@ int hpt_accum_download(hpt_ctx* ctx, const int64_t* accum_dev, int64_t* accum_ho
     return HPT_OK;
 }
 
-int hpt_accum_reduce(hpt_ctx* const* ctxs, int n, int root) {
+static int check_reduce_args(hpt_ctx* const* ctxs, int n, int root) {
     if (!ctxs || n < 1) return fail(HPT_ERR_INVALID_ARGUMENT, "hpt_accum_reduce: no contexts");
     if (root < 0 || root >= n) return fail(HPT_ERR_INVALID_ARGUMENT, "root %d not in [0, %d)", root, n);
     for (int i = 0; i < n; ++i) {
@@ -2128,25 +2187,53 @@ int hpt_accum_reduce(hpt_ctx* const* ctxs, int n, int root) {
         for (int j = 0; j < i; ++j)
             if (ctxs[j] == ctxs[i]) return fail(HPT_ERR_INVALID_ARGUMENT, "context %d is listed twice", i);
     }
+    return HPT_OK;
+}
+
+// one context index per distinct device, in order of first appearance: the root if it lives on that
+// device, else the first context listed there
+static std::vector<int> reduce_representatives(hpt_ctx* const* ctxs, int n, int root) {
+    std::vector<int> rep;
+    for (int i = 0; i < n; ++i) {
+        bool seen = false;
+        for (int k : rep)
+            if (ctxs[k]->device == ctxs[i]->device) seen = true;
+        if (!seen) rep.push_back(ctxs[root]->device == ctxs[i]->device ? root : i);
+    }
+    return rep;
+}
+
+static bool reduce_forced_through_rccl() {
+    const char* force = getenv("HPT_REDUCE_FORCE_RCCL");  // a one-device communicator all the same (tests on a one-GPU machine)
+    return force && atoi(force) != 0;
+}
+
+int hpt_accum_reduce_prepare(hpt_ctx* const* ctxs, int n) {
+    if (int rc = check_reduce_args(ctxs, n, 0)) return rc;
+    const std::vector<int> rep = reduce_representatives(ctxs, n, 0);
+    if (rep.size() == 1 && !reduce_forced_through_rccl()) return HPT_OK;
+    std::vector<int> devs;
+    for (int k : rep) devs.push_back(ctxs[k]->device);
+    std::lock_guard<std::mutex> lock(g_comm_mutex);
+    const CommSet* set = nullptr;
+    return comm_set_for(devs, &set);
+}
+
+int hpt_accum_reduce(hpt_ctx* const* ctxs, int n, int root) {
+    if (int rc = check_reduce_args(ctxs, n, root)) return rc;
     const size_t count = ctxs[root]->accum_elems;
     // every context's queued renders must have finished before another stream or device reads its buffer
     for (int i = 0; i < n; ++i) {
         HIP_TRY(hipSetDevice(ctxs[i]->device));
         HIP_TRY(hipDeviceSynchronize());
     }
-    // 1. contexts that share a device are summed there: into the root if it lives on that device,
-    //    else into the first of them (the device's representative)
-    std::vector<int> rep;  // one context index per distinct device
-    for (int i = 0; i < n; ++i) {
-        int r = -1;
-        for (int k : rep)
-            if (ctxs[k]->device == ctxs[i]->device) r = k;
-        if (r < 0) {
-            int pick = i;
-            if (ctxs[root]->device == ctxs[i]->device) pick = root;
-            rep.push_back(pick);
-        }
-    }
+    const auto t0 = std::chrono::steady_clock::now();
+    auto stamp = [&]() {
+        std::lock_guard<std::mutex> lock(g_comm_mutex);
+        g_last_reduce_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    };
+    // 1. contexts that share a device are summed there, into the device's representative
+    const std::vector<int> rep = reduce_representatives(ctxs, n, root);
     for (int i = 0; i < n; ++i) {
         int r = -1;
         for (int k : rep)
@@ -2159,10 +2246,11 @@ int hpt_accum_reduce(hpt_ctx* const* ctxs, int n, int root) {
         HIP_TRY(hipDeviceSynchronize());
     }
     // 2. one RCCL reduce (sum of int64, associative: the result does not depend on the order) over the
-    //    representatives; a single device needs none (HPT_REDUCE_FORCE_RCCL=1 runs it all the same)
-    const char* force = getenv("HPT_REDUCE_FORCE_RCCL");
-    if (rep.size() == 1 && !(force && atoi(force) != 0)) return HPT_OK;
-    if (int rc = load_rccl()) return rc;
+    //    representatives; a single device needs none
+    if (rep.size() == 1 && !reduce_forced_through_rccl()) {
+        stamp();
+        return HPT_OK;
+    }
     const int nd = (int)rep.size();
     std::vector<int> devs(nd);
     int root_rank = 0;
@@ -2170,32 +2258,36 @@ int hpt_accum_reduce(hpt_ctx* const* ctxs, int n, int root) {
         devs[k] = ctxs[rep[k]]->device;
         if (rep[k] == root) root_rank = k;
     }
-    std::vector<void*> comms(nd, nullptr);
-    RCCL_TRY(g_rccl.CommInitAll(comms.data(), nd, devs.data()));
-    int rc = HPT_OK;
-    do {
-        int r = g_rccl.GroupStart();
-        for (int k = 0; k < nd && r == 0; ++k) {
-            if (hipSetDevice(devs[k]) != hipSuccess) { r = -1; break; }
-            int64_t* buf = ctxs[rep[k]]->d_accum;
-            r = g_rccl.Reduce(buf, buf, count, /*ncclInt64*/ 4, /*ncclSum*/ 0, root_rank, comms[k], nullptr);
-        }
-        const int e = g_rccl.GroupEnd();
-        if (r == 0) r = e;
-        if (r != 0) {
-            rc = fail(HPT_ERR_HIP, "RCCL reduce failed: %s", r > 0 ? g_rccl.GetErrorString(r) : "hipSetDevice");
+    // the communicators of this device list: made by the first reduce over it (or by
+    // hpt_accum_reduce_prepare), reused by every later one.  The lock also keeps two reduces of one
+    // process from interleaving their grouped calls on the same communicators.
+    std::lock_guard<std::mutex> lock(g_comm_mutex);
+    const CommSet* set = nullptr;
+    if (int rc = comm_set_for(devs, &set)) return rc;
+    int r = g_rccl.GroupStart();
+    for (int k = 0; k < nd && r == 0; ++k) {
+        if (hipSetDevice(devs[k]) != hipSuccess) {
+            r = -1;
             break;
         }
-        for (int k = 0; k < nd; ++k) {
-            if (hipSetDevice(devs[k]) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
-                rc = fail(HPT_ERR_HIP, "synchronising device %d after the reduce failed", devs[k]);
-                break;
-            }
-        }
-    } while (false);
+        int64_t* buf = ctxs[rep[k]]->d_accum;
+        r = g_rccl.Reduce(buf, buf, count, /*ncclInt64*/ 4, /*ncclSum*/ 0, root_rank, set->comms[k], nullptr);
+    }
+    const int e = g_rccl.GroupEnd();
+    if (r == 0) r = e;
+    if (r != 0) return fail(HPT_ERR_HIP, "RCCL reduce failed: %s", r > 0 ? g_rccl.GetErrorString(r) : "hipSetDevice");
     for (int k = 0; k < nd; ++k)
-        if (comms[k]) (void)g_rccl.CommDestroy(comms[k]);
-    return rc;
+        if (hipSetDevice(devs[k]) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+            return fail(HPT_ERR_HIP, "synchronising device %d after the reduce failed", devs[k]);
+    g_last_reduce_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return HPT_OK;
+}
+
+int hpt_accum_reduce_info(uint64_t* communicators_created, double* last_reduce_ms) {
+    std::lock_guard<std::mutex> lock(g_comm_mutex);
+    if (communicators_created) *communicators_created = g_comm_created;
+    if (last_reduce_ms) *last_reduce_ms = g_last_reduce_ms;
+    return HPT_OK;
 }
 
 int hpt_octant_copies(const hpt_scene_desc* sc, int leaf_bits, float* nodes_out, uint32_t* table_out) {
@@ -2272,9 +2364,23 @@ int hpt_render_static(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t
     // clears on the stream before each single-kernel launch; the generate kernel writes every
     // live counter and every path record the bounce kernel reads.
     uint32_t launches = 0;
-    if (int rc = render_launch(ctx, mode, block, max_depth, sample_begin, sample_count, accum_dev ? accum_dev : ctx->d_accum,
-                               (hipStream_t)stream_, &buf, &launches))
+    hipStream_t stream = (hipStream_t)stream_;
+    // order this call after the previous one on this GPU, whatever context or stream that came from
+    // (the lock is held over the launches so that two host threads cannot interleave theirs)
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (stream && hipStreamIsCapturing(stream, &capturing) != hipSuccess) {
+        (void)hipGetLastError();
+        capturing = hipStreamCaptureStatusNone;
+    }
+    const bool ordered = capturing == hipStreamCaptureStatusNone;
+    if (ordered && g_scratch_event_recorded[ctx->device]) HIP_TRY(hipStreamWaitEvent(stream, g_scratch_event[ctx->device], 0));
+    if (int rc = render_launch(ctx, mode, block, max_depth, sample_begin, sample_count, accum_dev ? accum_dev : ctx->d_accum, stream, &buf, &launches))
         return rc;
+    if (ordered) {
+        HIP_TRY(hipEventRecord(g_scratch_event[ctx->device], stream));
+        g_scratch_event_recorded[ctx->device] = true;
+    }
     ctx->launches += launches;
     return HPT_OK;
 }

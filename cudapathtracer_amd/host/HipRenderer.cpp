@@ -40,8 +40,15 @@ void HipRenderer::PrepareRender(const Scene& scene) {
         check(hpt_set_bvh_build(c, scene.flat().gpu_build ? HPT_BVH_BUILD_GPU : HPT_BVH_BUILD_HOST), "hpt_set_bvh_build");
         check(hpt_scene_upload(c, &desc), "hpt_scene_upload");
     }
+    if (!extra_ctx.empty()) {
+        // the communicators of the reduce are made here, once, so that Render's clock holds a reduce and not a bootstrap
+        std::vector<hpt_ctx*> all{ctx};
+        all.insert(all.end(), extra_ctx.begin(), extra_ctx.end());
+        check(hpt_accum_reduce_prepare(all.data(), (int)all.size()), "hpt_accum_reduce_prepare");
+    }
     framebuffer.assign(num_pixels, Vec3(0.f));
     framebuffer_stale = false;
+    reduce_pending = false;
     next_sample = 0;
 }
 
@@ -66,6 +73,7 @@ void HipRenderer::RefreshFramebuffer() {
         check(hpt_accum_reduce(all.data(), (int)all.size(), 0), "hpt_accum_reduce");
         for (hpt_ctx* c : extra_ctx) check(hpt_accum_clear(c, nullptr, nullptr), "hpt_accum_clear");  // their samples now live in ctx
         reduce_pending = false;
+        check(hpt_accum_reduce_info(nullptr, &last_reduce_ms), "hpt_accum_reduce_info");
     }
     check(hpt_resolve(ctx, nullptr, (uint32_t)(this->spp > 0 ? this->spp : 1), &framebuffer[0].x, nullptr), "hpt_resolve");
     framebuffer_stale = false;
@@ -102,6 +110,10 @@ void HipRenderer::Render(const Scene& scene) {
                 for (const std::string& e : errors)
                     if (!e.empty()) throw std::runtime_error("hpt_render: " + e);
                 check(hpt_accum_reduce(all.data(), (int)G, 0), "hpt_accum_reduce");
+                // the other contexts' samples now live in ctx: a later PathTrace + reduce must not count them again
+                for (hpt_ctx* c : extra_ctx) check(hpt_accum_clear(c, nullptr, nullptr), "hpt_accum_clear");
+                reduce_pending = false;
+                check(hpt_accum_reduce_info(nullptr, &last_reduce_ms), "hpt_accum_reduce_info");
             }
             next_sample = (unsigned)this->spp;
             static_assert(sizeof(Vec3) == 3 * sizeof(float), "Vec3 must be three packed floats");

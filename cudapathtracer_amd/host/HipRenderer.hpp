@@ -53,4 +53,5 @@ public:
     // ray counters and kernel time since PrepareRender
     hpt_stats Stats();
     double last_render_seconds = 0.0;
+    double last_reduce_ms = 0.0;  // host time of the last cross-context reduce (several `devices` only)
 };

@@ -361,10 +361,12 @@ const FlatScene& Scene::flat() const {
 
 hpt_ctx* Scene::queryContext() const {
     const FlatScene& f = flat();
+    if (query_ctx_ && query_ctx_device_ != query_device) query_ctx_.reset();  // the caller moved the queries to another GPU: upload there
     if (!query_ctx_) {
         hpt_ctx* ctx = nullptr;
         if (hpt_context_create(query_device, &ctx) != HPT_OK) throw std::runtime_error(std::string("Scene: ") + hpt_last_error());
         query_ctx_ = std::shared_ptr<hpt_ctx>(ctx, [](hpt_ctx* c) { hpt_context_destroy(c); });
+        query_ctx_device_ = query_device;
         const hpt_scene_desc d = describe();
         if (hpt_set_bvh_build(ctx, f.gpu_build ? HPT_BVH_BUILD_GPU : HPT_BVH_BUILD_HOST) != HPT_OK || hpt_scene_upload(ctx, &d) != HPT_OK) {
             query_ctx_.reset();

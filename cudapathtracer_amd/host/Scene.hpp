@@ -153,5 +153,6 @@ private:
     void fillMaterialsAndLights(FlatScene& fs) const;
     hpt_ctx* queryContext() const;
     mutable std::shared_ptr<hpt_ctx> query_ctx_;   // intersect() / castRay(): created and uploaded on first use
+    mutable int query_ctx_device_ = -1;            // the GPU query_ctx_ lives on (recreated when query_device changes)
     mutable std::vector<int32_t> tri_of_prim_;     // global primitive id -> triangle record
 };

@@ -79,6 +79,7 @@ int main(int argc, char** argv) {
         if (r.last_render_seconds > 0)
             std::cout << "Rays: " << rays << " (" << rays / r.last_render_seconds * 1e-6 << " Mrays/s, " << spp / r.last_render_seconds
                       << " spp/s)\n";
+        if (r.devices.size() > 1) std::cout << "Reduce over " << r.devices.size() << " GPUs: " << r.last_reduce_ms << " ms (inside the time above)\n";
 
         Utility::SavePPM("out/gpu/" + scene.name + ".ppm", r.framebuffer, scene.width, scene.height);
         if (getenv("HPT_PFM")) Utility::SavePFM("out/gpu/" + scene.name + ".pfm", r.framebuffer, scene.width, scene.height);

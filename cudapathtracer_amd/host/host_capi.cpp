@@ -236,7 +236,22 @@ int hpt_host_render_devices(const hpt_host_scene* s, const int* devices, int num
         r.SetMode((HipRenderMode)mode);
         r.num_threads = num_threads;
         r.PrepareRender(sc);
-        if (iterative) {
+        if (iterative == 2) {
+            // Render the first half of the samples, then add the rest one PathTrace at a time: the flow of a
+            // caller that refines a finished picture (framebuffer = accumulated / spp, so spp is raised first)
+            const int first = spp / 2;
+            r.spp = first;
+            std::streambuf* old = std::cout.rdbuf(nullptr);
+            try {
+                r.Render(sc);
+            } catch (...) {
+                std::cout.rdbuf(old);
+                throw;
+            }
+            std::cout.rdbuf(old);
+            r.spp = spp;
+            for (int iter = first; iter < spp; ++iter) r.PathTrace(sc, iter);
+        } else if (iterative) {
             for (int iter = 0; iter < spp; ++iter) r.PathTrace(sc, iter);
         } else {
             std::streambuf* old = std::cout.rdbuf(nullptr);

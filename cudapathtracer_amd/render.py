@@ -95,8 +95,13 @@ def main(argv=None):
     render_sharded(trace, accum, args.spp, rank, world, dist=dist if world > 1 else None, dst=0)
     st = ctx.stats()
     rays = torch.tensor([float(st["closest_queries"] + st["shadow_queries"])], dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(rays.to(dev) if args.backend == "nccl" else rays)
+    if world > 1:   # the rays of all ranks (RCCL reduces device tensors, gloo host tensors; both in place)
+        if args.backend == "nccl":
+            on_dev = rays.to(dev)
+            dist.all_reduce(on_dev)
+            rays = on_dev.cpu()
+        else:
+            dist.all_reduce(rays)
     if rank == 0:
         img = ctx.resolve(max(args.spp, 1), accum=accum, stream=stream)
         dt = time.perf_counter() - t0
@@ -106,7 +111,7 @@ def main(argv=None):
         hp.SavePPM(out, img, args.width, args.height)
         if args.pfm:
             hp.SavePFM(args.pfm, img, args.width, args.height)
-        print("%s: %d spp on %d GPU(s), %.1f Mrays/s of this rank's clock" % (out, args.spp, world, float(rays.item()) / dt * 1e-6))
+        print("%s: %d spp on %d GPU(s), %.1f Mrays/s (the rays of all ranks over rank 0's clock)" % (out, args.spp, world, float(rays.item()) / dt * 1e-6))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

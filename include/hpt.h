@@ -236,8 +236,11 @@ int hpt_render(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sample
  *   Limit: at most 2^18 = 262 144 camera paths per call, counted as
  *   ceil(width/8) * ceil(height/8) * 64 * sample_count (512 x 512 pixels x 1 sample, 64 x 64 x 64
  *   samples, ...); beyond that the call returns HPT_ERR_TOO_LARGE and does nothing.
- *   All calls on one GPU share that GPU's array, whatever their context or stream: calls that
- *   overlap on one GPU race.  Queue them on one stream, or order them with events. */
+ *   All calls on one GPU share that GPU's array, whatever their context or stream.  The library orders
+ *   them itself: a call makes its stream wait for the previous hpt_render_static on that GPU (one event
+ *   per GPU, created with the GPU's first context; nothing is allocated in the call) -- so calls from
+ *   several contexts or streams are safe but run one after the other.  A stream under graph capture is
+ *   not ordered this way (an event recorded there belongs to the graph): keep such calls on one stream. */
 int hpt_render_static(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sample_begin, uint32_t sample_count,
                       int64_t* accum_dev, void* stream);
 
@@ -316,6 +319,17 @@ int hpt_accum_download(hpt_ctx* ctx, const int64_t* accum_dev, int64_t* accum_ho
  * one GPU each reduce hpt_accum_buffer() with their own communicator instead (torch.distributed / RCCL:
  * cudapathtracer_amd/sharding.py). */
 int hpt_accum_reduce(hpt_ctx* const* ctxs, int n, int root);
+
+/* The RCCL communicators hpt_accum_reduce uses are kept: one set per ordered list of distinct devices,
+ * created by the first reduce over that list and reused by every later one, destroyed together with the
+ * process's last context.  hpt_accum_reduce_prepare creates the set for these contexts ahead of the first
+ * reduce (HipRenderer::PrepareRender calls it, so that Render's clock holds a reduce, not a communicator
+ * bootstrap); it does nothing when all contexts share one device.  hpt_accum_reduce_info reports how many
+ * sets the process has created so far and the host time of the last reduce (ms: same-device adds, the
+ * collective and the waits after it).  No counterpart in the reference (one GPU,
+ * gpu_path_tracer/CudaRenderer.hpp:18). */
+int hpt_accum_reduce_prepare(hpt_ctx* const* ctxs, int n);
+int hpt_accum_reduce_info(uint64_t* communicators_created, double* last_reduce_ms);
 
 /* Host-only (no GPU, no context): the nine per-octant node-array copies that hpt_scene_upload
  * derives for scenes of up to 64 triangles, for inspection and for tests of the claim they rest

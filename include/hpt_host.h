@@ -73,7 +73,9 @@ int hpt_host_render_iterative(const hpt_host_scene* s, int device, int spp, int 
                               float* rgb, hpt_stats* stats);
 /* The same with the samples sharded over the GPUs listed (HipRenderer::devices; an index may repeat):
  * one host thread per entry renders a contiguous sample range, hpt_accum_reduce sums the buffers
- * onto devices[0].  iterative != 0: through PathTrace, sample iter on entry iter mod num_devices. */
+ * onto devices[0].  iterative = 1: through PathTrace, sample iter on entry iter mod num_devices;
+ * iterative = 2: Render() with spp / 2 samples, then PathTrace for the remaining ones (a finished picture
+ * that is refined further; every sample must be counted once). */
 int hpt_host_render_devices(const hpt_host_scene* s, const int* devices, int num_devices, int spp, int max_depth,
                             int num_threads, int mode, int iterative, float* rgb, hpt_stats* stats);
 /* A third way to build the scene's tree, on the host like HPT_BVH_BUILD_HOST (the device library sees an ordinary

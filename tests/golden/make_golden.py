@@ -142,6 +142,43 @@ def large_scenes(R):
     R.cornell(5)
 
 
+def scene_images(R):
+    """Converged-ish pictures of the bunny and height-field scenes by the reference renderer, with their noise
+    floor: per scene two independent 64-spp renders at 96 x 96, depth 20 (Scene::castRay per camera path through
+    the reference's own Scene / BVHAccel, as for the Cornell box's r96_d20 pair).  Stored: render a, the channel
+    means of render b, the RMSE between the two (plain and on values clamped to [0, 1])."""
+    import tempfile
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from cudapathtracer_amd import scenes
+    cases = [("bunny", scenes.bunny_in_cornell_parts()), ("heightfield64", scenes.heightfield_in_cornell_parts(64)),
+             ("heightfield708", scenes.heightfield_in_cornell_parts(708))]
+    g = {}
+    w = h = 96
+    P = w * h
+    for tag, parts in cases:
+        with tempfile.TemporaryDirectory() as tmp:
+            R.begin(w, h, 20, CAM, 40.0)
+            for name, tris, mat in parts:
+                path = os.path.join(tmp, name + ".obj")
+                write_obj(path, tris)
+                R.add_obj(path, Material.make(**mat))
+            R.build()
+        a = np.zeros((P, 3), np.float64)
+        b = np.zeros((P, 3), np.float64)
+        for s in range(64):
+            a += R.cast_paths(np.full(P, s), np.arange(P))
+            b += R.cast_paths(np.full(P, 64 + s), np.arange(P))
+        a, b = (a / 64).astype(np.float32), (b / 64).astype(np.float32)
+        g[tag + "_r96_d20_spp64_a"] = a
+        g[tag + "_r96_d20_spp64_b_mean"] = b.mean(0)
+        ca, cb = np.clip(a, 0, 1), np.clip(b, 0, 1)
+        g[tag + "_r96_d20_noise_rmse_clamped"] = np.array([np.sqrt(((ca - cb) ** 2).mean())], np.float64)
+        g[tag + "_r96_d20_noise_rmse"] = np.array([np.sqrt(((a - b) ** 2).mean())], np.float64)
+        print(tag, "noise floor (clamped)", g[tag + "_r96_d20_noise_rmse_clamped"][0], "means", a.mean(0), b.mean(0), flush=True)
+    np.savez_compressed(os.path.join(HERE, "scene_images.npz"), **g)
+    R.cornell(5)
+
+
 def extras(R):
     """solveQuadratic (common/MathUtils.hpp:86-100, the live half of the commented-out Sphere) and
     Material::regularize (common/Material.hpp:164-171) of the compiled reference."""
@@ -167,6 +204,8 @@ def main():
         return glass(R)
     if sys.argv[1:] == ["scenes"]:
         return large_scenes(R)
+    if sys.argv[1:] == ["scene_images"]:
+        return scene_images(R)
     info = R.info()
     assert info["num_tris"] == 32 and info["node_counter"] == 69
 

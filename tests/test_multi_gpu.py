@@ -57,6 +57,51 @@ def test_accum_reduce_of_contexts_in_one_process(hp, oracle, monkeypatch, force_
             c.close()
 
 
+def test_second_reduce_reuses_the_communicator(hp, monkeypatch):
+    """The RCCL communicators of hpt_accum_reduce are made once per device list and kept: the first reduce (or
+    hpt_accum_reduce_prepare) creates them, every later reduce over the same devices is one grouped ncclReduce."""
+    w, h, depth = 32, 32, 4
+    sc = hp.Scene.CreateBuiltinScene(hp.Scene.CornellBox, depth, w, h)
+    monkeypatch.setenv("HPT_REDUCE_FORCE_RCCL", "1")   # one GPU here: a communicator of one device all the same
+    ctxs = [hp.Context(0).upload(sc) for _ in range(2)]
+    try:
+        before, _ = hp.accum_reduce_info()
+        hp.accum_reduce_prepare(ctxs)
+        made, _ = hp.accum_reduce_info()
+        assert made == before + 1
+        for rnd in range(3):
+            for k, c in enumerate(ctxs):
+                c.accum_clear()
+                c.render(1, 256, depth, 2 * rnd + k, 1)
+            hp.accum_reduce(ctxs, root=0)
+            n, ms = hp.accum_reduce_info()
+            assert n == made, "reduce %d created a communicator" % rnd
+            assert ms > 0
+            got = ctxs[0].accum_download()
+            ctxs[1].accum_clear()
+            ctxs[1].render(2, 256, depth, 2 * rnd, 2)
+            assert np.array_equal(got, ctxs[1].accum_download())
+        # another root over the same devices: still the same communicator set
+        hp.accum_reduce(ctxs, root=1)
+        assert hp.accum_reduce_info()[0] == made
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_render_then_pathtrace_counts_every_sample_once(hp, mode):
+    """HipRenderer with several devices: Render() reduces the other contexts' buffers into the first; samples added
+    afterwards with PathTrace() and reduced again must not bring Render()'s shares along a second time."""
+    w, h, depth, spp = 48, 40, 6, 9
+    sc = hp.Scene.CreateBuiltinScene(hp.Scene.CornellBox, depth, w, h)
+    one, _ = sc.render_cpp(spp, depth, 256, mode)
+    for devices in ([0, 0], [0, 0, 0]):
+        refined, st = sc.render_cpp(spp, depth, 256, mode, devices=devices, iterative=2)
+        assert st["paths"] == w * h * spp
+        assert np.array_equal(one.view(np.int32), refined.view(np.int32)), devices
+
+
 @pytest.mark.parametrize("mode", [1, 2])
 def test_cpp_renderer_sharded_over_devices(hp, mode):
     w, h, depth, spp = 64, 48, 6, 5
@@ -109,6 +154,17 @@ def test_bench_two_ranks_and_rccl_backend():
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
     assert line["config"]["collective_backend"] == "gloo"
+    assert line["config"]["world_size"] == 2 and [r["rank"] for r in line["config"]["ranks"]] == [0, 1]
+    assert line["config"]["reduce_ms"] is not None and line["config"]["reduce_bytes"] == 3 * 128 * 128 * 8
+    leg = line["strong_config"]   # the 4096-spp job split over the two ranks, beside the weak line
+    assert leg["scaling"] == "strong" and leg["n_gpus"] == 2 and leg["paths"] == leg["paths_expected"] == 128 * 128 * 4096
+    # the same program with --scaling strong: total work fixed, split over steps and ranks
+    r = subprocess.run(cmd + ["--scaling", "strong", "--total-spp", "7", "--steps", "2"], cwd=ROOT, env=_env(HPT_BENCH_BACKEND="gloo", HPT_BENCH_DEVICE="0"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=110)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["scaling"] == "strong" and line["n_gpus"] == 2 and line["steps"] == 2 and line["strong_config"] is None
+    assert "7 spp in all" in line["config"]["workload"] and line["config"]["world_size"] == 2
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, cwd=ROOT, env=_env(HPT_BENCH_FORCE_DIST="1", MASTER_PORT="29561"),
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=110)
     assert r.returncode == 0, r.stderr[-3000:]
