@@ -46,7 +46,8 @@ class hpt_scene_desc(C.Structure):
                 ("num_materials", C.c_uint32), ("materials", C.POINTER(hpt_material)),
                 ("num_lights", C.c_uint32), ("lights", C.POINTER(hpt_light)),
                 ("sum_light_area", C.c_float), ("sum_light_power", C.c_float),
-                ("cam_pos", C.c_float * 3), ("cam_scale", C.c_float), ("width", C.c_int32), ("height", C.c_int32)]
+                ("cam_pos", C.c_float * 3), ("cam_scale", C.c_float), ("width", C.c_int32), ("height", C.c_int32),
+                ("num_ref_nodes", C.c_uint32), ("ref_nodes", C.POINTER(C.c_float))]
 
 
 class hpt_stats(C.Structure):
@@ -197,7 +198,7 @@ def _stream(stream):
 
 
 TRAVERSAL_REFERENCE, TRAVERSAL_CULLED = 0, 1
-BVH_BUILD_HOST, BVH_BUILD_GPU, BVH_BUILD_SAH = 0, 1, 2
+BVH_BUILD_HOST, BVH_BUILD_GPU, BVH_BUILD_SAH, BVH_BUILD_AUTO = 0, 1, 2, 3
 INTEGRATOR_RUSSIAN_ROULETTE, INTEGRATOR_REGULARIZE = 1, 2
 
 
@@ -326,6 +327,7 @@ class Scene:
             node_area=np.ctypeslib.as_array(d.node_area, (nn,)).copy(),
             tris=np.ctypeslib.as_array(d.tris, (nt, 16)).copy(),
             tri_v12=np.ctypeslib.as_array(d.tri_v12, (nt, 8)).copy(),
+            ref_nodes=np.ctypeslib.as_array(d.ref_nodes, (d.num_ref_nodes, 8)).copy() if d.num_ref_nodes else None,
             prim_of_tri=prim,
             materials=np.array([(m.type,) + tuple(m.emission) + tuple(m.albedo) + (m.metallic, m.roughness, m.ior)
                                 for m in (d.materials[i] for i in range(d.num_materials))], np.float32),

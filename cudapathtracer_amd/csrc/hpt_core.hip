@@ -1056,6 +1056,7 @@ struct hpt_ctx {
     float4* d_tris = nullptr;
     float4* d_tri_v12 = nullptr;
     float4* d_pairs = nullptr;
+    float4* d_ref_nodes = nullptr;  // the reference's tree beside the caller's (threaded walk through L1/L2 only)
     float4* d_oct_nodes = nullptr;
     uint32_t* d_oct_table = nullptr;
     DevMaterial* d_mats = nullptr;
@@ -1101,6 +1102,8 @@ void free_scene(hpt_ctx* ctx) {
     (void)hipFree(ctx->d_tris);
     (void)hipFree(ctx->d_tri_v12);
     (void)hipFree(ctx->d_pairs);
+    (void)hipFree(ctx->d_ref_nodes);
+    ctx->d_ref_nodes = nullptr;
     (void)hipFree(ctx->d_oct_nodes);
     (void)hipFree(ctx->d_oct_table);
     (void)hipFree(ctx->d_mats);
@@ -1169,25 +1172,34 @@ int validate_scene(const hpt_scene_desc* sc) {
         if (sc->materials[m].type < 0 || sc->materials[m].type > 2)
             return fail(HPT_ERR_INVALID_ARGUMENT, "material %u: type %d is none of 0 Lambertian, 1 MetallicWorkflow, 2 Glass", m,
                         sc->materials[m].type);
-    const int32_t nn = (int32_t)sc->num_nodes;
-    std::vector<uint8_t> tri_seen(sc->num_tris, 0);
-    for (int32_t i = 0; i < nn; ++i) {
-        int32_t miss, tri;
-        std::memcpy(&miss, &sc->nodes[8 * (size_t)i + 3], 4);
-        std::memcpy(&tri, &sc->nodes[8 * (size_t)i + 7], 4);
-        if (miss <= i || miss > nn) return fail(HPT_ERR_INVALID_ARGUMENT, "node %d: miss link %d does not point forward", i, miss);
-        if (tri >= (int32_t)sc->num_tris) return fail(HPT_ERR_INVALID_ARGUMENT, "node %d: triangle %d out of range", i, tri);
-        if (tri >= 0) {
-            if (miss != i + 1) return fail(HPT_ERR_INVALID_ARGUMENT, "leaf %d: miss link must be the next node", i);
-            tri_seen[tri] = 1;
-        } else {
-            // interior: left child = i+1, right child = miss link of the left child
-            if (i + 1 >= nn) return fail(HPT_ERR_INVALID_ARGUMENT, "interior node %d has no children", i);
-            int32_t lmiss;
-            std::memcpy(&lmiss, &sc->nodes[8 * (size_t)(i + 1) + 3], 4);
-            if (lmiss <= i + 1 || lmiss >= nn || lmiss >= miss)
-                return fail(HPT_ERR_INVALID_ARGUMENT, "interior node %d: right child %d outside its subtree", i, lmiss);
+    auto check_tree = [&](const float* nodes, uint32_t num_nodes, const char* name) -> int {
+        const int32_t nn = (int32_t)num_nodes;
+        for (int32_t i = 0; i < nn; ++i) {
+            int32_t miss, tri;
+            std::memcpy(&miss, &nodes[8 * (size_t)i + 3], 4);
+            std::memcpy(&tri, &nodes[8 * (size_t)i + 7], 4);
+            if (miss <= i || miss > nn) return fail(HPT_ERR_INVALID_ARGUMENT, "%s %d: miss link %d does not point forward", name, i, miss);
+            if (tri >= (int32_t)sc->num_tris) return fail(HPT_ERR_INVALID_ARGUMENT, "%s %d: triangle %d out of range", name, i, tri);
+            if (tri >= 0) {
+                if (miss != i + 1) return fail(HPT_ERR_INVALID_ARGUMENT, "%s %d (a leaf): miss link must be the next node", name, i);
+            } else {
+                // interior: left child = i+1, right child = miss link of the left child
+                if (i + 1 >= nn) return fail(HPT_ERR_INVALID_ARGUMENT, "interior %s %d has no children", name, i);
+                int32_t lmiss;
+                std::memcpy(&lmiss, &nodes[8 * (size_t)(i + 1) + 3], 4);
+                if (lmiss <= i + 1 || lmiss >= nn || lmiss >= miss)
+                    return fail(HPT_ERR_INVALID_ARGUMENT, "interior %s %d: right child %d outside its subtree", name, i, lmiss);
+            }
         }
+        return HPT_OK;
+    };
+    if (int rc = check_tree(sc->nodes, sc->num_nodes, "node")) return rc;
+    if (sc->num_ref_nodes || sc->ref_nodes) {
+        if (!sc->ref_nodes || sc->num_ref_nodes == 0 || sc->num_ref_nodes > (1u << 30)) return fail(HPT_ERR_INVALID_ARGUMENT, "ref_nodes and num_ref_nodes must be given together");
+        if (int rc = check_tree(sc->ref_nodes, sc->num_ref_nodes, "ref_node")) return rc;
+        // both trees stand over the same leaves, so their roots' boxes are the same min/max of the same numbers
+        if (std::memcmp(sc->nodes, sc->ref_nodes, 12) != 0 || std::memcmp(sc->nodes + 4, sc->ref_nodes + 4, 12) != 0)
+            return fail(HPT_ERR_INVALID_ARGUMENT, "nodes and ref_nodes have different root boxes: they are not trees over the same leaves");
     }
     for (uint32_t t = 0; t < sc->num_tris; ++t) {
         int32_t mat;
@@ -1229,10 +1241,15 @@ int validate_scene(const hpt_scene_desc* sc) {
 // tests with probability q(parent) - q(node).  The Cornell box goes from 17.6 to 10.2 box tests
 // per ray.  Copy 8 (rays with a zero direction component, for which the argument does not
 // hold: 0 * inf = NaN) always keeps the reference's tree.
-void build_octant_copies(const hpt_scene_desc* sc, bool leaf_bits, std::vector<float>& out_nodes, std::vector<uint32_t>& out_table) {
-    const uint32_t nn = sc->num_nodes, nt = sc->num_tris;
+void build_octant_copies(const hpt_scene_desc* sc_in, bool leaf_bits, std::vector<float>& out_nodes, std::vector<uint32_t>& out_table) {
+    const uint32_t nn = sc_in->num_nodes, nt = sc_in->num_tris;
     out_nodes.assign((size_t)9 * nn * 8, 0.f);
     out_table.assign(32, 0u);
+    // copy 8 (rays with a zero direction component) is the REFERENCE's tree: `ref_nodes` when the scene brings one
+    // (then `nodes` is some other tree over the same leaves; the caller has checked that both have nn nodes)
+    hpt_scene_desc whole_desc = *sc_in;
+    if (sc_in->ref_nodes) whole_desc.nodes = sc_in->ref_nodes;
+    const hpt_scene_desc* sc = sc_in;
     auto node_int = [&](uint32_t i, int word) {
         int32_t v;
         std::memcpy(&v, &sc->nodes[8 * (size_t)i + word], 4);
@@ -1257,6 +1274,7 @@ void build_octant_copies(const hpt_scene_desc* sc, bool leaf_bits, std::vector<f
     if (const char* e = getenv("HPT_OCTANT_TREES")) nested = nested && atoi(e) != 0;  // 0: keep the reference's topology (A/B runs)
     for (uint32_t k = 0; k < 9; ++k) {
         const bool whole = k == 8;
+        if (whole) sc = &whole_desc;
         const float sgn[3] = {(k & 1u) ? -1.f : 1.f, (k & 2u) ? -1.f : 1.f, (k & 4u) ? -1.f : 1.f};
         std::vector<uint8_t> rejected(nt, 0), passes(nt, 0);
         if (!whole)
@@ -1935,9 +1953,10 @@ int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* sc) {
     }
     // Two-child records of the same tree (see DevScene::pairs).  Interior node i has the children
     // i + 1 and miss(i + 1); records are numbered in pre-order of the interior nodes.
-    uint32_t num_pairs = 0, stack_depth = 1, stack_depth_any = 1;
+    uint32_t num_pairs = 0, stack_depth = 1, stack_depth_any = 1, ref_root = 0;
     float root_lo[3] = {sc->nodes[0], sc->nodes[1], sc->nodes[2]}, root_hi[3] = {sc->nodes[4], sc->nodes[5], sc->nodes[6]};
     const bool gpu_build = ctx->bvh_build == HPT_BVH_BUILD_GPU;
+    if (gpu_build && sc->ref_nodes) return fail(HPT_ERR_INVALID_ARGUMENT, "HPT_BVH_BUILD_GPU builds its own records: a scene with ref_nodes must be uploaded with HPT_BVH_BUILD_HOST");
     if (gpu_build) {
         // the records come from the triangle array alone (csrc/hpt_bvh_build.hip); `nodes` only serves the light sampling
         if (nt < 2) return fail(HPT_ERR_INVALID_ARGUMENT, "HPT_BVH_BUILD_GPU needs at least two primitives");
@@ -1957,42 +1976,65 @@ int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* sc) {
                                                        (uint32_t)nn, ctx->d_pairs, &stack_depth, &stack_depth_any, root_lo, root_hi, &ctx->bvh_build_ms);
         if (!err.empty()) return fail(HPT_ERR_HIP, "GPU BVH build: %s", err.c_str());
     } else {
-        auto node_int = [&](size_t i, int word) {
-            int32_t v;
-            std::memcpy(&v, &sc->nodes[8 * i + word], 4);
-            return v;
-        };
-        std::vector<int32_t> pair_of(nn, -1);
-        for (size_t i = 0; i < nn; ++i)
-            if (node_int(i, 7) < 0) pair_of[i] = (int32_t)num_pairs++;
-        if (num_pairs) {
-            std::vector<float> rec((size_t)num_pairs * 16);
-            std::vector<uint32_t> need(num_pairs, 0);  // stack entries a walk below this record can hold at once
-            std::vector<uint32_t> need_any(num_pairs, 0);  // the same when either child may be walked first
-            for (size_t i = nn; i-- > 0;) {
+        // records of one tree, appended to `rec`; child references count from the start of `rec`
+        auto derive = [&](const float* nodes, size_t n_nodes, std::vector<float>& rec, uint32_t& need0, uint32_t& need_any0) -> uint32_t {
+            auto node_int = [&](size_t i, int word) {
+                int32_t v;
+                std::memcpy(&v, &nodes[8 * i + word], 4);
+                return v;
+            };
+            const uint32_t first = (uint32_t)(rec.size() / 16);
+            uint32_t count = 0;
+            std::vector<int32_t> pair_of(n_nodes, -1);
+            for (size_t i = 0; i < n_nodes; ++i)
+                if (node_int(i, 7) < 0) pair_of[i] = (int32_t)(first + count++);
+            need0 = need_any0 = 1u;
+            if (!count) return 0u;
+            rec.resize((size_t)(first + count) * 16);
+            std::vector<uint32_t> need(count, 0);      // stack entries a walk below this record can hold at once
+            std::vector<uint32_t> need_any(count, 0);  // the same when either child may be walked first
+            for (size_t i = n_nodes; i-- > 0;) {
                 if (pair_of[i] < 0) continue;
                 const size_t l = i + 1, r = (size_t)node_int(l, 3);
                 float* q = &rec[(size_t)pair_of[i] * 16];
                 const int32_t tl = node_int(l, 7), tr = node_int(r, 7);
                 const int32_t ref_l = tl >= 0 ? ~tl : pair_of[l], ref_r = tr >= 0 ? ~tr : pair_of[r];
                 for (int c = 0; c < 3; ++c) {
-                    q[c] = sc->nodes[8 * l + c];
-                    q[4 + c] = sc->nodes[8 * l + 4 + c];
-                    q[8 + c] = sc->nodes[8 * r + c];
-                    q[12 + c] = sc->nodes[8 * r + 4 + c];
+                    q[c] = nodes[8 * l + c];
+                    q[4 + c] = nodes[8 * l + 4 + c];
+                    q[8 + c] = nodes[8 * r + c];
+                    q[12 + c] = nodes[8 * r + 4 + c];
                 }
                 std::memcpy(&q[3], &ref_l, 4);
                 std::memcpy(&q[7], &ref_r, 4);
                 q[11] = q[15] = 0.f;
                 // the right child waits on the stack while the left subtree is walked
-                const uint32_t nl = ref_l >= 0 ? need[ref_l] + (ref_r >= 0 ? 1u : 0u) : 0u;
-                const uint32_t nr = ref_r >= 0 ? need[ref_r] : 0u;
-                need[pair_of[i]] = std::max(nl, nr);
+                const uint32_t me = (uint32_t)pair_of[i] - first;
+                const uint32_t nl = ref_l >= 0 ? need[(uint32_t)ref_l - first] + (ref_r >= 0 ? 1u : 0u) : 0u;
+                const uint32_t nr = ref_r >= 0 ? need[(uint32_t)ref_r - first] : 0u;
+                need[me] = std::max(nl, nr);
                 const uint32_t both = (ref_l >= 0 && ref_r >= 0) ? 1u : 0u;
-                need_any[pair_of[i]] = std::max(ref_l >= 0 ? need_any[ref_l] : 0u, ref_r >= 0 ? need_any[ref_r] : 0u) + both;
+                need_any[me] = std::max(ref_l >= 0 ? need_any[(uint32_t)ref_l - first] : 0u, ref_r >= 0 ? need_any[(uint32_t)ref_r - first] : 0u) + both;
             }
-            stack_depth = std::max(1u, need[0]);
-            stack_depth_any = std::max(1u, need_any[0]);
+            need0 = std::max(1u, need[0]);
+            need_any0 = std::max(1u, need_any[0]);
+            return count;
+        };
+        std::vector<float> rec;
+        num_pairs = derive(sc->nodes, nn, rec, stack_depth, stack_depth_any);
+        if (sc->ref_nodes && num_pairs) {
+            // The reference's own tree behind the caller's: rays with a zero direction component start at its root
+            // (DevScene::ref_root).  For them a box test can come out NaN-false whatever the boxes' nesting, so which
+            // leaves they reach depends on the tree; every other ray reaches the same leaves in any tree over them.
+            uint32_t d1 = 1, d2 = 1;
+            ref_root = num_pairs;
+            const uint32_t more = derive(sc->ref_nodes, sc->num_ref_nodes, rec, d1, d2);
+            if (!more) ref_root = 0;
+            num_pairs += more;
+            stack_depth = std::max(stack_depth, d1);
+            stack_depth_any = std::max(stack_depth_any, d2);
+        }
+        if (num_pairs) {
             ALLOC_TRY(ctx->d_pairs, rec.size() * 4, "pairs");
             HIP_TRY(hipMemcpy(ctx->d_pairs, rec.data(), rec.size() * 4, hipMemcpyHostToDevice));
         }
@@ -2040,8 +2082,10 @@ int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* sc) {
     const uint64_t f4_tiny = 18ull * nn + 4ull * nt + 8ull;  // nine copies of the nodes + triangles + table
     const uint64_t f4_pair = 4ull * num_pairs + 4ull * nt;  // two-child records + triangles
     // records built on the GPU: `nodes` is not the scene's tree, so only the two-child-record walks apply
-    const bool fits = !gpu_build && f4 * 16ull <= kLdsLimit, fits_pair = f4_pair * 16ull <= kLdsLimit;
-    const bool fits_tiny = !gpu_build && f4_tiny * 16ull <= kLdsLimitTiny;
+    // (a scene that brings the reference's tree beside its own: the threaded walk from LDS has no second array, and
+    // the octant copies take their ninth copy from it, which must then have as many nodes as the others)
+    const bool fits = !gpu_build && !sc->ref_nodes && f4 * 16ull <= kLdsLimit, fits_pair = f4_pair * 16ull <= kLdsLimit;
+    const bool fits_tiny = !gpu_build && f4_tiny * 16ull <= kLdsLimitTiny && (!sc->ref_nodes || sc->num_ref_nodes == sc->num_nodes);
     const bool pair_ok = num_pairs > 0 && stack_depth <= kMaxStackDepth;
     const bool tiny_ok = fits_tiny && !ctx->has_sphere;  // the marking variants test triangles only
     if (tiny_ok && nt <= 32) S.variant = kSceneTiny32;
@@ -2096,6 +2140,15 @@ int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* sc) {
         HIP_TRY(hipMemcpy(ctx->d_oct_table, oct_table.data(), oct_table.size() * 4, hipMemcpyHostToDevice));
         S.oct_nodes = ctx->d_oct_nodes;
         S.oct_table = ctx->d_oct_table;
+    }
+    S.ref_root = ref_root;
+    S.ref_nodes = S.nodes;
+    S.num_ref_nodes = S.num_nodes;
+    if (sc->ref_nodes && S.variant == kSceneGlobal) {
+        ALLOC_TRY(ctx->d_ref_nodes, (size_t)sc->num_ref_nodes * 32, "ref_nodes");
+        HIP_TRY(hipMemcpy(ctx->d_ref_nodes, sc->ref_nodes, (size_t)sc->num_ref_nodes * 32, hipMemcpyHostToDevice));
+        S.ref_nodes = ctx->d_ref_nodes;
+        S.num_ref_nodes = sc->num_ref_nodes;
     }
     switch (S.variant) {
     case kSceneLds: S.lds_float4s = (uint32_t)f4; break;

@@ -296,6 +296,13 @@ struct DevScene {
     uint32_t integrator;
     float roulette_q;
     uint32_t has_spheres;  // some record of `tris` is a sphere (then word 15 is the mesh index everywhere, never a group mask)
+    // A scene may bring the reference's own tree beside the one `nodes` / `pairs` hold (any tree over the same leaves
+    // reaches the same triangles for a ray whose three reciprocal direction components are finite; a ray with a zero
+    // component can fail a box test on a NaN whatever the nesting, so for it the tree matters): such rays start their
+    // walk at record `ref_root` of `pairs` (the reference tree's records lie behind the others; 0 = one tree only),
+    // the threaded walk of kSceneGlobal reads `ref_nodes` (= `nodes` when there is one tree only).
+    uint32_t ref_root, num_ref_nodes;
+    const float4* ref_nodes;
 };
 enum : uint32_t { kIntegratorRoulette = 1u, kIntegratorRegularize = 2u };
 // word 15 of a record of the triangle array with this bit set: the record is a sphere
@@ -644,7 +651,6 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
     int best = -1;
     double best_t = (double)kInfinity;
     int node = 0;
-    const int end = (int)S.num_nodes;
     if constexpr (kScene == kSceneTiny32 || kScene == kSceneTiny64) {
         constexpr bool kMask32 = (kScene != kSceneTiny64);
         using mask_t = typename std::conditional<kMask32, uint32_t, unsigned long long>::type;
@@ -791,7 +797,8 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
             float tn, tf;
             cur = (box_range_finite(rlo, rhi, o, inv, tn, tf) && tf >= behind && tn <= cull_t) ? 0 : -1;
         } else {
-            cur = (finite ? box_hit_finite(rlo, rhi, o, inv) : box_hit(rlo, rhi, o, inv, nx, ny, nz)) ? 0 : -1;
+            // (a ray with a zero direction component walks the reference's own tree: DevScene::ref_root)
+            cur = finite ? (box_hit_finite(rlo, rhi, o, inv) ? 0 : -1) : (box_hit(rlo, rhi, o, inv, nx, ny, nz) ? (int)S.ref_root : -1);
         }
         uint32_t cnt = 0, sp = 0;
         COUNT_BOX(1);  // the root's box
@@ -886,6 +893,13 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
         const float kInf = __builtin_inff();
         const bool finite = fabsf(inv.x) < kInf && fabsf(inv.y) < kInf && fabsf(inv.z) < kInf;
         uint32_t cnt = 0;
+        int end = (int)S.num_nodes;
+        if constexpr (kScene == kSceneGlobal) {
+            if (!finite) {  // a ray with a zero direction component walks the reference's own tree
+                N = S.ref_nodes;
+                end = (int)S.num_ref_nodes;
+            }
+        }
         for (;;) {
             while (node < end && cnt < kTriQueue) {
                 COUNT_BOX(1);
@@ -975,7 +989,7 @@ HD void walk_begin(const DevScene& S, Walk& W, f3 o, f3 d, bool shadow, float tm
     } else {
         hit = W.finite ? box_hit_finite(rlo, rhi, o, W.inv) : box_hit(rlo, rhi, o, W.inv, d.x < 0, d.y < 0, d.z < 0);
     }
-    W.cur = hit ? 0 : -1;
+    W.cur = hit ? (W.finite ? 0 : (int)S.ref_root) : -1;  // a ray with a zero direction component walks the reference's own tree
 }
 
 // visit record W.cur (requires walk_can_step): test both children's boxes, queue the leaves that

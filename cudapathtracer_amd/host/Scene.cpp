@@ -22,7 +22,7 @@ float luminance(Vec3 c) { return dot(c, Vec3(.2126f, .7152f, .0722f)); }
 void put_int(float* dst, int32_t v) { std::memcpy(dst, &v, 4); }
 }  // namespace
 
-Scene::BvhBuild Scene::default_bvh_build = Scene::BvhBuild::Reference;
+Scene::BvhBuild Scene::default_bvh_build = Scene::BvhBuild::Auto;
 
 // light bookkeeping as common/Scene.hpp:47-56
 void Scene::Add(Sphere* sphere) {
@@ -68,7 +68,11 @@ void Scene::buildBVH() {
     // reference's subtree: Scene::sampleLight descends it).  Small non-emitting meshes (walls, boxes: up to
     // kExplode triangles) enter the top level as individual triangles instead of as one object each: their
     // room-sized boxes would otherwise all be entered by every ray.
-    const bool sah = bvh_build == BvhBuild::Sah;
+    // Auto: Sah for scenes of more than 64 primitives (the ones whose records are read through the caches), else
+    // Reference (the device keeps such scenes in LDS under trees of its own making).
+    size_t num_prims = 0;
+    for (const ObjectRef& o : objects) num_prims += o.sphere ? 1u : meshes[o.index]->triangles.size();
+    const bool sah = bvh_build == BvhBuild::Sah || (bvh_build == BvhBuild::Auto && num_prims > 64);
     constexpr size_t kExplode = 64;
     struct TopItem {
         int obj;  // index into `objects`
@@ -91,22 +95,28 @@ void Scene::buildBVH() {
             top_objects.push_back(whole);
         }
     }
+    // `bvh` and `mesh_bvhs` -- the members the reference's Scene shows its callers -- are the reference's trees
+    // whatever is emitted; the surface-area trees only live until the records are written.
     mesh_bvh_owner_.clear();
     mesh_bvhs.clear();
+    std::vector<std::shared_ptr<BVHAccel>> emit_mesh;  // the tree each mesh is emitted with
     for (MeshTriangle* m : meshes) {
         std::vector<Object*> tris(m->triangles.size());
         for (size_t i = 0; i < tris.size(); ++i) tris[i] = &m->triangles[i];
-        mesh_bvh_owner_.push_back(std::make_shared<BVHAccel>(tris, 1, sah && !m->material.emitting() ? BVHAccel::SplitMethod::SAH : BVHAccel::SplitMethod::NAIVE));
+        mesh_bvh_owner_.push_back(std::make_shared<BVHAccel>(tris, 1, BVHAccel::SplitMethod::NAIVE));
         mesh_bvhs.push_back(mesh_bvh_owner_.back().get());
+        const bool exploded = sah && !m->material.emitting() && m->triangles.size() <= kExplode;  // no subtree of its own is emitted
+        emit_mesh.push_back(sah && !m->material.emitting() && !exploded ? std::make_shared<BVHAccel>(tris, 1, BVHAccel::SplitMethod::SAH) : mesh_bvh_owner_.back());
     }
-    // the top level orders its children by the stack their subtrees need, the meshes' subtrees included
+    bvh_owner_ = std::make_shared<BVHAccel>(ref_objects, 1, BVHAccel::SplitMethod::NAIVE);
+    bvh = bvh_owner_.get();
+    // the emitted top level orders its children by the stack their subtrees need, the meshes' subtrees included
     std::vector<int32_t> leaf_need(items.size(), -1);
     for (size_t i = 0; i < items.size(); ++i) {
         const ObjectRef& o = objects[(size_t)items[i].obj];
-        if (items[i].tri < 0 && !o.sphere && meshes[o.index]->triangles.size() > 1) leaf_need[i] = mesh_bvhs[o.index]->stackNeed();
+        if (items[i].tri < 0 && !o.sphere && meshes[o.index]->triangles.size() > 1) leaf_need[i] = emit_mesh[o.index]->stackNeed();
     }
-    bvh_owner_ = std::make_shared<BVHAccel>(top_objects, 1, sah ? BVHAccel::SplitMethod::SAH : BVHAccel::SplitMethod::NAIVE, sah ? &leaf_need : nullptr);
-    bvh = bvh_owner_.get();
+    const std::shared_ptr<BVHAccel> emit_top = sah ? std::make_shared<BVHAccel>(top_objects, 1, BVHAccel::SplitMethod::SAH, &leaf_need) : bvh_owner_;
     // primitive ids count through the objects in Add order (a sphere is one primitive)
     std::vector<int32_t> object_base(objects.size());
     int32_t base = 0;
@@ -116,13 +126,13 @@ void Scene::buildBVH() {
     }
 
     // global index of every top-level node once the mesh subtrees are spliced in
-    const std::vector<FlatNode>& top = bvh->nodes;
+    const std::vector<FlatNode>& top = emit_top->nodes;
     std::vector<int32_t> top_to_global(top.size() + 1);
     int32_t cursor = 0;
     for (size_t t = 0; t < top.size(); ++t) {
         top_to_global[t] = cursor;
         const bool mesh_leaf = top[t].object >= 0 && items[top[t].object].tri < 0 && !objects[items[top[t].object].obj].sphere;
-        cursor += mesh_leaf ? (int32_t)mesh_bvhs[objects[items[top[t].object].obj].index]->nodes.size() : 1;
+        cursor += mesh_leaf ? (int32_t)emit_mesh[objects[items[top[t].object].obj].index]->nodes.size() : 1;
     }
     top_to_global[top.size()] = cursor;
     const uint32_t num_nodes = (uint32_t)cursor, num_tris = (uint32_t)base;
@@ -140,25 +150,17 @@ void Scene::buildBVH() {
     // A triangle's record index is its rank in the REFERENCE's traversal order (top-level leaves in the order the
     // reference's top-level tree meets them, then the mesh's leaves in the order its reference tree meets them),
     // whatever tree is emitted: among triangles hit at bitwise the same distance the kernels keep the lowest record
-    // index, which is then the triangle the reference's strict `<` keeps (common/BVH.hpp:128-137).  For the
-    // reference build these are the trees just built; the SAH build makes the reference's trees once more for it.
+    // index, which is then the triangle the reference's strict `<` keeps (common/BVH.hpp:128-137).
     std::vector<int32_t> rec_base(objects.size(), 0);
     std::vector<std::vector<int32_t>> rec_of_tri(meshes.size());
     {
-        std::shared_ptr<BVHAccel> top_ref = sah ? std::make_shared<BVHAccel>(ref_objects, 1, BVHAccel::SplitMethod::NAIVE) : bvh_owner_;
         int32_t next = 0;
-        for (int32_t obj : top_ref->leafOrder()) {
+        for (int32_t obj : bvh_owner_->leafOrder()) {
             rec_base[obj] = next;
             next += objects[obj].sphere ? 1 : meshes[objects[obj].index]->num_triangles;
         }
         for (size_t k = 0; k < meshes.size(); ++k) {
-            std::shared_ptr<BVHAccel> ref = mesh_bvh_owner_[k];
-            if (ref->splitMethod != BVHAccel::SplitMethod::NAIVE) {
-                std::vector<Object*> tris(meshes[k]->triangles.size());
-                for (size_t i = 0; i < tris.size(); ++i) tris[i] = &meshes[k]->triangles[i];
-                ref = std::make_shared<BVHAccel>(tris, 1, BVHAccel::SplitMethod::NAIVE);
-            }
-            const std::vector<int32_t> order = ref->leafOrder();
+            const std::vector<int32_t> order = mesh_bvh_owner_[k]->leafOrder();
             rec_of_tri[k].assign(order.size(), 0);
             for (size_t i = 0; i < order.size(); ++i) rec_of_tri[k][(size_t)order[i]] = (int32_t)i;
         }
@@ -213,7 +215,7 @@ void Scene::buildBVH() {
             write_node(g0, tn.bounds, top_to_global[tn.miss], rec, tn.area);
             continue;
         }
-        const std::vector<FlatNode>& mn = mesh_bvhs[k]->nodes;
+        const std::vector<FlatNode>& mn = emit_mesh[k]->nodes;
         // The reference tests the mesh's bounding box (top-level leaf) and then
         // the identical box of the nested root; one test gives the same answer.
         const Bounds3 rb = mn[0].bounds, mb = mesh->bounding_box;
@@ -231,6 +233,41 @@ void Scene::buildBVH() {
         }
     }
 
+    if (sah) {
+        // The reference's own two-level tree, flattened the same way, beside the emitted one: rays with a zero
+        // direction component walk it on the device (hpt_scene_desc::ref_nodes says why), so every ray gets the
+        // reference's answer although `nodes` holds another tree.
+        const std::vector<FlatNode>& rt = bvh_owner_->nodes;
+        std::vector<int32_t> to_global(rt.size() + 1);
+        int32_t at = 0;
+        for (size_t t = 0; t < rt.size(); ++t) {
+            to_global[t] = at;
+            const bool mesh_leaf = rt[t].object >= 0 && !objects[(size_t)rt[t].object].sphere;
+            at += mesh_leaf ? (int32_t)mesh_bvhs[objects[(size_t)rt[t].object].index]->nodes.size() : 1;
+        }
+        to_global[rt.size()] = at;
+        fs->num_ref_nodes = (uint32_t)at;
+        fs->ref_nodes.resize(8ull * fs->num_ref_nodes);
+        auto write_ref = [&](int32_t g, const Bounds3& b, int32_t miss, int32_t tri) {
+            float* n = fs->ref_nodes.data + 8ull * g;
+            n[0] = b.pMin.x; n[1] = b.pMin.y; n[2] = b.pMin.z; put_int(n + 3, miss);
+            n[4] = b.pMax.x; n[5] = b.pMax.y; n[6] = b.pMax.z; put_int(n + 7, tri);
+        };
+        for (size_t t = 0; t < rt.size(); ++t) {
+            const FlatNode& tn = rt[t];
+            const int32_t g0 = to_global[t];
+            if (tn.object < 0) {
+                write_ref(g0, tn.bounds, to_global[tn.miss], -1);
+            } else if (objects[(size_t)tn.object].sphere) {
+                write_ref(g0, tn.bounds, to_global[tn.miss], rec_base[tn.object]);
+            } else {
+                const int k = objects[(size_t)tn.object].index;
+                const std::vector<FlatNode>& mn = mesh_bvhs[k]->nodes;
+                for (size_t i = 0; i < mn.size(); ++i)
+                    write_ref(g0 + (int32_t)i, mn[i].bounds, g0 + mn[i].miss, mn[i].object >= 0 ? rec_base[tn.object] + rec_of_tri[k][(size_t)mn[i].object] : -1);
+            }
+        }
+    }
     fs->sah_build = sah;
     fillMaterialsAndLights(*fs);
     flat_ = fs;
@@ -470,6 +507,8 @@ hpt_scene_desc Scene::describe() const {
     d.cam_scale = cameraScale();
     d.width = width;
     d.height = height;
+    d.num_ref_nodes = f.num_ref_nodes;
+    d.ref_nodes = f.num_ref_nodes ? f.ref_nodes.data : nullptr;
     return d;
 }
 

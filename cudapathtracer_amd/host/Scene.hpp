@@ -26,6 +26,8 @@ struct AlignedFloats {
 // triangles in leaf order.  Record formats are documented at hpt_scene_desc.
 struct FlatScene {
     AlignedFloats nodes, node_area, tris, tri_v12;
+    AlignedFloats ref_nodes;              // sah_build: the reference's own tree beside `nodes` (hpt_scene_desc::ref_nodes)
+    uint32_t num_ref_nodes = 0;
     std::vector<hpt_material> materials;  // one per mesh, Scene::Add order
     std::vector<hpt_light> lights;        // emitting meshes, Scene::Add order
     std::vector<int32_t> prim_of_tri;     // leaf order -> global primitive id
@@ -47,9 +49,9 @@ public:
     int maxDepth = 1;
     float RussianRoulette = 0.8f;  // unused (enableRR = false, common/Scene.hpp:142)
 
-    BVHAccel* bvh = nullptr;              // top level, over meshes
+    BVHAccel* bvh = nullptr;              // top level, over meshes: the reference's tree, whatever tree the flattened records hold
     std::vector<MeshTriangle*> meshes;    // Scene::Add order
-    std::vector<BVHAccel*> mesh_bvhs;     // per mesh, same order
+    std::vector<BVHAccel*> mesh_bvhs;     // per mesh, same order: the reference's trees
     int num_meshes = 0;
     float sumLightArea = 0.0f;
     float sumLightPower = 0.0f;
@@ -73,17 +75,19 @@ public:
     // Gpu: only the trees of the emitting meshes are built here (Scene::sampleLight descends them); the traversal
     // records for the whole scene are built on the device at upload (HPT_BVH_BUILD_GPU in include/hpt.h says what
     // that guarantees).  `bvh` and the mesh_bvhs of non-emitting meshes stay null then.
-    // Sah: the two-level BVH on the host like Reference, but the top level and every mesh that does not emit are split
-    // by the surface-area heuristic (BVHAccel::SplitMethod::SAH, which the reference declares without implementing,
-    // common/BVH.hpp:28) and their children ordered so that the traversal stack stays short; emitting meshes keep the
-    // reference's tree, which Scene::sampleLight descends.  The leaves (one triangle each, same boxes) are the
+    // Sah: the flattened records hold ANOTHER tree over the same leaves: the top level and every mesh that does not emit
+    // are split by the surface-area heuristic (BVHAccel::SplitMethod::SAH, which the reference declares without
+    // implementing, common/BVH.hpp:28) and their children ordered so that the traversal stack stays short; emitting meshes
+    // keep the reference's tree, which Scene::sampleLight descends.  The leaves (one triangle each, same boxes) are the
     // reference's, so every ray with finite reciprocal direction components tests the same triangles and gets the
-    // same closest distance and occlusion answer; the triangle records stay in the reference's traversal order (the
-    // reference's trees are built once more for that), so of several triangles hit at bitwise equal distance the one
-    // the reference names is named.  Fewer boxes are tested on the way: 11-16 % more rays per second on the bunny and
-    // the 1.0 M-triangle height field.  What is not covered: a ray with a zero direction component whose origin lies
-    // exactly on a box plane (0 * inf = NaN in the slab test), where the reference's answer depends on its tree.
-    enum class BvhBuild { Reference, Gpu, Sah };
+    // same closest distance and occlusion answer; the triangle records stay in the reference's traversal order,
+    // so of several triangles hit at bitwise equal distance the one the reference names is named; and the reference's
+    // own tree is emitted beside the other (FlatScene::ref_nodes) for the rays that argument leaves out -- those with a
+    // zero direction component, whose slab tests can fail on 0 * inf = NaN -- which walk it on the device.  So every
+    // result is the reference's, with fewer boxes tested on the way: 11-16 % more rays per second on the bunny and the
+    // 1.0 M-triangle height field.  `bvh` and `mesh_bvhs` stay the reference's trees.
+    // Auto (default): Sah for scenes of more than 64 primitives, else Reference.
+    enum class BvhBuild { Reference, Gpu, Sah, Auto };
     static BvhBuild default_bvh_build;  // what new scenes start with (the built-in scenes build inside their factory)
     BvhBuild bvh_build = default_bvh_build;
     void buildBVH();

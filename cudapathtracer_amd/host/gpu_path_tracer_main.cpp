@@ -11,7 +11,8 @@
 //   HPT_DEVICE               GPU index (default 0)
 //   HPT_GPUS=N               shard the samples over GPUs 0..N-1 (one RCCL reduce sums the accumulators)
 //   HPT_DEVICES=0,1,3        the same over the GPUs listed (an index may repeat: rehearsal on one GPU)
-//   HPT_BVH=gpu                    build the traversal records on the GPU (median split, one tree for the scene)
+//   HPT_BVH=gpu | sah | reference  traversal records built on the GPU / surface-area tree / the reference's tree alone
+//                                  (default "auto": surface-area tree for scenes of more than 64 primitives; same pictures)
 //   HPT_INTEGRATOR=rr,regularize   Russian roulette / path regularisation as the reference writes them (off there)
 //   HPT_SCENE                bunny | glass | heightfield:<n> | file:<scene file> instead of the reference's Cornell box
 #include <cstdlib>
@@ -35,8 +36,9 @@ int main(int argc, char** argv) {
     try {
         // HPT_SCENE=bunny / glass / heightfield:<n> / file:<path> renders another scene than the reference's only one
         const char* which = getenv("HPT_SCENE");
-        if (const char* b = getenv("HPT_BVH"))  // "gpu": traversal records built on the device at upload; "sah": surface-area splits on the host
-            Scene::default_bvh_build = std::string(b) == "gpu" ? Scene::BvhBuild::Gpu : std::string(b) == "sah" ? Scene::BvhBuild::Sah : Scene::BvhBuild::Reference;
+        if (const char* b = getenv("HPT_BVH"))  // "gpu": traversal records built on the device at upload; "sah": surface-area splits on the host; anything else but "auto": the reference's tree
+            Scene::default_bvh_build = std::string(b) == "gpu" ? Scene::BvhBuild::Gpu : std::string(b) == "sah" ? Scene::BvhBuild::Sah
+                                       : std::string(b) == "auto" ? Scene::BvhBuild::Auto : Scene::BvhBuild::Reference;
         Scene scene = Scene::CreateNamedScene(which ? which : "cornell", maxDepth);
         if (const char* w = getenv("HPT_WIDTH")) scene.width = atoi(w);
         if (const char* h = getenv("HPT_HEIGHT")) scene.height = atoi(h);

@@ -293,24 +293,26 @@ static bool to_bvh_build(int build, Scene::BvhBuild* out) {
     if (build == HPT_BVH_BUILD_HOST) *out = Scene::BvhBuild::Reference;
     else if (build == HPT_BVH_BUILD_GPU) *out = Scene::BvhBuild::Gpu;
     else if (build == HPT_HOST_BVH_BUILD_SAH) *out = Scene::BvhBuild::Sah;
+    else if (build == HPT_HOST_BVH_BUILD_AUTO) *out = Scene::BvhBuild::Auto;
     else return false;
     return true;
 }
 
 int hpt_host_set_default_bvh_build(int build) {
-    if (!to_bvh_build(build, &Scene::default_bvh_build)) return fail("build is none of HPT_BVH_BUILD_HOST, HPT_BVH_BUILD_GPU, HPT_HOST_BVH_BUILD_SAH");
+    if (!to_bvh_build(build, &Scene::default_bvh_build)) return fail("build is none of HPT_BVH_BUILD_HOST, HPT_BVH_BUILD_GPU, HPT_HOST_BVH_BUILD_SAH, HPT_HOST_BVH_BUILD_AUTO");
     return 0;
 }
 
 int hpt_host_default_bvh_build(int* build) {
     if (!build) return fail("null argument");
-    *build = Scene::default_bvh_build == Scene::BvhBuild::Gpu ? HPT_BVH_BUILD_GPU : Scene::default_bvh_build == Scene::BvhBuild::Sah ? HPT_HOST_BVH_BUILD_SAH : HPT_BVH_BUILD_HOST;
+    *build = Scene::default_bvh_build == Scene::BvhBuild::Gpu ? HPT_BVH_BUILD_GPU : Scene::default_bvh_build == Scene::BvhBuild::Sah ? HPT_HOST_BVH_BUILD_SAH
+           : Scene::default_bvh_build == Scene::BvhBuild::Auto ? HPT_HOST_BVH_BUILD_AUTO : HPT_BVH_BUILD_HOST;
     return 0;
 }
 
 int hpt_host_scene_set_bvh_build(hpt_host_scene* s, int build) {
     if (!s) return fail("scene is null");
-    if (!to_bvh_build(build, &s->scene.bvh_build)) return fail("build is none of HPT_BVH_BUILD_HOST, HPT_BVH_BUILD_GPU, HPT_HOST_BVH_BUILD_SAH");
+    if (!to_bvh_build(build, &s->scene.bvh_build)) return fail("build is none of HPT_BVH_BUILD_HOST, HPT_BVH_BUILD_GPU, HPT_HOST_BVH_BUILD_SAH, HPT_HOST_BVH_BUILD_AUTO");
     return 0;
 }
 

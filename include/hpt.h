@@ -79,7 +79,8 @@ typedef struct {
  *   whose leaves are the reference's (one triangle or sphere each): a ray with finite reciprocal direction
  *   components that hits a leaf's box hits every box that encloses it, so the triangles tested -- and with them
  *   distances, occlusion answers and pictures -- do not depend on the interior nodes.  The host library's
- *   Scene::BvhBuild::Sah emits such a tree (surface-area splits, fewer boxes tested per ray).  The light table's
+ *   Scene::BvhBuild::Sah emits such a tree (surface-area splits, fewer boxes tested per ray), with the reference's
+ *   tree beside it in `ref_nodes` for the rays the argument leaves out.  The light table's
  *   root_node subtrees must be the reference's mesh trees: BVHAccel::getSample descends them.
  * tris: in leaf order of the REFERENCE's tree (= the order the reference traversal meets them; equal-t
  *   ties resolve to the lower index, as the strict `<` of common/BVH.hpp:130 does; a tree of another
@@ -113,6 +114,14 @@ typedef struct {
     float cam_pos[3];       /* Scene::camPos */
     float cam_scale;        /* tan(fov/2) as the host renderer computes it (common/Renderer.cpp:20) */
     int32_t width, height;  /* Scene::width/height; aspect = width/(float)height */
+    /* Optional (0 / NULL: `nodes` IS the reference's tree).  When `nodes` holds another tree over the same leaves
+     * (surface-area splits), the reference's own flattened tree (common/BVH.cpp:81-168), in the format of `nodes`
+     * with leaf words that index the same `tris`.  Rays with a zero direction component walk THIS tree: for them a
+     * slab test can fail on 0 * inf = NaN whatever the boxes' nesting (common/Bounds3.hpp:93-118), so the leaves
+     * they reach depend on the interior nodes, and with the reference's nodes they reach the reference's.  Every
+     * other ray walks `nodes`.  With it, a scene with any tree in `nodes` gives the reference's results for every ray. */
+    uint32_t num_ref_nodes;
+    const float* ref_nodes; /* [num_ref_nodes][8] */
 } hpt_scene_desc;
 
 typedef struct {

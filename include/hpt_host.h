@@ -83,10 +83,15 @@ int hpt_host_render_devices(const hpt_host_scene* s, const int* devices, int num
  * for the top level and every mesh that does not emit, with the children ordered for a short traversal stack; emitting
  * meshes keep the reference's tree (Scene::sampleLight descends it).  Same leaves as the reference's tree and the
  * triangle records in the reference's traversal order: distances, occlusion answers AND primitive ids are the
- * reference's for every ray with finite reciprocal direction components; fewer boxes are tested per ray. */
+ * reference's for every ray with finite reciprocal direction components; fewer boxes are tested per ray.  The rays
+ * that leaves out (a zero direction component) walk the reference's own tree, which the scene description carries
+ * beside the other (hpt_scene_desc::ref_nodes): every result is the reference's.
+ * HPT_HOST_BVH_BUILD_AUTO (the default): HPT_HOST_BVH_BUILD_SAH for scenes of more than 64 primitives, else
+ * HPT_BVH_BUILD_HOST (such scenes are kept in LDS under trees the device library makes itself). */
 #define HPT_HOST_BVH_BUILD_SAH 2
-/* Scene::default_bvh_build: scenes created from now on flatten for HPT_BVH_BUILD_HOST (default), HPT_BVH_BUILD_GPU
- * (include/hpt.h) or HPT_HOST_BVH_BUILD_SAH; the renderer picks the matching upload. */
+#define HPT_HOST_BVH_BUILD_AUTO 3
+/* Scene::default_bvh_build: scenes created from now on flatten for HPT_HOST_BVH_BUILD_AUTO (default), HPT_BVH_BUILD_HOST,
+ * HPT_BVH_BUILD_GPU (include/hpt.h) or HPT_HOST_BVH_BUILD_SAH; the renderer picks the matching upload. */
 int hpt_host_set_default_bvh_build(int build);
 int hpt_host_default_bvh_build(int* build);
 /* Scene::bvh_build of one scene (takes effect at its next hpt_host_scene_build), and how the scene was last built */

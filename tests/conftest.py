@@ -35,11 +35,12 @@ def ref():
 def hp():
     import cudapathtracer_amd
     cudapathtracer_amd.load_libraries()
-    # HPT_TEST_BVH=sah: every scene the tests create without naming a builder gets the surface-area tree (a
-    # diagnostic run of the whole suite on the other tree; tests that compare the tree itself with the reference's
-    # fail by design)
-    if os.environ.get("HPT_TEST_BVH") == "sah":
-        cudapathtracer_amd.api._ckh(cudapathtracer_amd.load_libraries()[1].hpt_host_set_default_bvh_build(cudapathtracer_amd.BVH_BUILD_SAH))
+    # HPT_TEST_BVH=sah | reference: every scene the tests create without naming a builder gets the surface-area tree
+    # (also the small ones, which by default keep the reference's) / the reference's tree alone -- runs of the whole
+    # suite on either tree; the default is "auto" (surface-area tree for scenes of more than 64 primitives)
+    which = {"sah": cudapathtracer_amd.BVH_BUILD_SAH, "reference": cudapathtracer_amd.BVH_BUILD_HOST}.get(os.environ.get("HPT_TEST_BVH", ""))
+    if which is not None:
+        cudapathtracer_amd.api._ckh(cudapathtracer_amd.load_libraries()[1].hpt_host_set_default_bvh_build(which))
     return cudapathtracer_amd
 
 

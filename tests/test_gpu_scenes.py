@@ -58,6 +58,37 @@ def _shadow_batch(n, seed, down=False):
     return (p + d * np.float32(1e-5)).astype(np.float32), d, np.ones(n, np.uint8), ln.astype(np.float64)
 
 
+def _zero_component_rays(parts, n, seed):
+    """Rays with one or two zero direction components (infinite reciprocals: 0 * inf = NaN in the slab test, the case
+    in which the leaves a ray reaches depend on the interior nodes of the tree), a third of them starting exactly ON
+    planes of leaf boxes (at vertices of the scene's triangles), the rest at random points."""
+    rs = np.random.RandomState(seed)
+    verts = np.concatenate([np.asarray(t, np.float32).reshape(-1, 3) for _, t, _ in parts])
+    o = (rs.rand(n, 3) * [556, 548.8, 559.2]).astype(np.float32)
+    pick = rs.rand(n) < 1.0 / 3.0
+    o[pick] = verts[rs.randint(0, len(verts), int(pick.sum()))]
+    half = rs.rand(n) < 0.5          # of those, half are moved off the vertex along one axis only (still on two planes)
+    o[pick & half, rs.randint(0, 3)] += np.float32(3.0)
+    dirs = []
+    for a in range(3):
+        for sgn in (1.0, -1.0):
+            v = np.zeros(3, np.float32)
+            v[a] = sgn
+            dirs.append(v)                       # two zero components
+    for a in range(3):
+        for k in range(6):
+            ang = rs.rand() * 2 * np.pi
+            v = np.zeros(3, np.float32)
+            v[(a + 1) % 3], v[(a + 2) % 3] = np.cos(ang), np.sin(ang)
+            if k == 0:
+                v[a] = -0.0                      # a negative zero: dirIsNeg is false for it, the reciprocal is -inf
+            dirs.append(v)                       # one zero component
+    dirs = np.array(dirs, np.float32)
+    dirs /= np.sqrt((dirs.astype(np.float64) ** 2).sum(1))[:, None].astype(np.float32)
+    d = dirs[rs.randint(0, len(dirs), n)]
+    return o, np.ascontiguousarray(d, np.float32)
+
+
 @pytest.mark.parametrize("name", ["bunny", "heightfield128", "heightfield8", "heightfield4"])
 def test_scene_hits_and_images(hp, oracle, gpu_ctx, name):
     """bunny / heightfield128: two-child records read through L1/L2; heightfield8 (140 triangles):
@@ -76,7 +107,12 @@ def test_scene_hits_and_images(hp, oracle, gpu_ctx, name):
     base = sum(len(p[1]) for p in parts[:big])
     assert (hit >= base).mean() > 0.05, "the large mesh is in view"
     _same_hits(gpu_ctx, osc, *random_rays(1 << 17, 31))
+    # rays with zero direction components, many of them starting on planes of leaf boxes: the default build of the
+    # larger scenes is a surface-area tree, and these rays must walk the reference's own tree beside it
+    zo, zd = _zero_component_rays(parts, 1 << 15, 33)
+    assert (_same_hits(gpu_ctx, osc, zo, zd) >= 0).mean() > 0.3
     same = _same_hits if gpu_ctx.stats()["variant"] in (2, 3) else _same_occlusion
+    same(gpu_ctx, osc, zo, zd, np.ones(len(zo), np.uint8), np.full(len(zo), 300.0))
     occ = same(gpu_ctx, osc, *_shadow_batch(1 << 16, 32, down=(name != "bunny")))
     assert 0.02 < (occ >= 0).mean() <= 1.0
     want_acc, ost = osc.render(RNG_PHILOX, TRIG_PORTABLE, depth, spp, fixed=True)
@@ -179,13 +215,14 @@ def test_forced_variants(hp, oracle, gpu_ctx, monkeypatch, variant, sah):
     parts = scenes.heightfield_in_cornell_parts(8)
     w, h, depth, spp = 40, 24, 5, 2
     sc = scenes._assemble(parts, w, h, depth)
-    if sah:
-        sc.buildBVH(sah=True)
+    sc.buildBVH(sah=True) if sah else sc.buildBVH(gpu=False)
     osc = _oracle_scene(oracle, parts, w, h)
     monkeypatch.setenv("HPT_TRACE_VARIANT", str(variant))
     gpu_ctx.upload(sc)
     monkeypatch.delenv("HPT_TRACE_VARIANT")
-    assert gpu_ctx.stats()["variant"] == variant
+    # (the threaded walk from LDS holds one node array: a scene that brings the reference's tree beside its own
+    # keeps its two-child-record walk, which holds both)
+    assert gpu_ctx.stats()["variant"] == (6 if (variant == 1 and sah) else variant)
     _same_hits(gpu_ctx, osc, *random_rays(1 << 16, 51))
     _same_hits(gpu_ctx, osc, *primary_rays(128, 128, scenes.CORNELL_CAM, osc.info()["cam_scale"]))
     (_same_occlusion if sah else _same_hits)(gpu_ctx, osc, *_shadow_batch(1 << 15, 52, down=True))
@@ -840,20 +877,28 @@ def test_sah_build_renders_the_reference_results(hp, oracle, gpu_ctx, name):
         sc = hp.Scene(w, h, camPos=scenes.CORNELL_CAM, fov=40.0, maxDepth=depth)
         for _, tris, mat in parts:
             sc.Add(tris, hp.Material(**mat))
-        sc.buildBVH()
         osc = _oracle_scene(oracle, parts, w, h)
+    sc.buildBVH(gpu=False)   # the reference's tree alone
+    assert sc.bvh_build == hp.BVH_BUILD_HOST
     gpu_ctx.upload(sc)
     ref_info, ref_variant = gpu_ctx.build_info(), gpu_ctx.stats()["variant"]
     sc.buildBVH(sah=True)
     assert sc.bvh_build == hp.BVH_BUILD_SAH
     gpu_ctx.upload(sc)
     info = gpu_ctx.build_info()
-    assert gpu_ctx.stats()["variant"] == ref_variant and info["gpu_build_ms"] == 0 and info["records"] == ref_info["records"]
+    assert gpu_ctx.stats()["variant"] == ref_variant and info["gpu_build_ms"] == 0
+    # the two-child-record walks hold the records of both trees (the reference's behind the surface-area tree's, for
+    # the rays with a zero direction component); the stack serves the deeper of the two, i.e. the reference's
+    assert info["records"] == 2 * ref_info["records"]
     assert info["stack_depth"] <= ref_info["stack_depth"], (info, ref_info)
     # ids too: the records lie in the reference's traversal order, so ties go to the triangle the reference names
     o, d = primary_rays(192, 192, scenes.CORNELL_CAM, osc.info()["cam_scale"])
     _same_hits(gpu_ctx, osc, o, d)
     _same_hits(gpu_ctx, osc, *random_rays(1 << 17, 41))
+    if name != "spheres":
+        zo, zd = _zero_component_rays(parts, 1 << 15, 43)
+        _same_hits(gpu_ctx, osc, zo, zd)
+        (_same_hits if ref_variant in (2, 3) else _same_occlusion)(gpu_ctx, osc, zo, zd, np.ones(len(zo), np.uint8), np.full(len(zo), 250.0))
     _same_occlusion(gpu_ctx, osc, *_shadow_batch(1 << 16, 42, down=name.startswith("heightfield")))
     want_acc, ost = osc.render(RNG_PHILOX, TRIG_PORTABLE, depth, spp, fixed=True)
     for mode in (1, 2):
@@ -879,8 +924,8 @@ def test_sah_build_of_the_million_triangle_scene(hp, gpu_ctx):
     gpu_ctx.accum_clear()
     gpu_ctx.render(2, 256, 5, 0, 1)
     img = gpu_ctx.accum_download()
-    gpu_ctx.upload(hp.Scene.CreateNamedScene("heightfield:708", 5, 64, 64))
-    assert info["stack_depth"] <= gpu_ctx.build_info()["stack_depth"] and info["records"] == gpu_ctx.build_info()["records"]
+    gpu_ctx.upload(hp.Scene.CreateNamedScene("heightfield:708", 5, 64, 64, bvh_build=hp.BVH_BUILD_HOST))
+    assert info["stack_depth"] <= gpu_ctx.build_info()["stack_depth"] and info["records"] == 2 * gpu_ctx.build_info()["records"]
     assert _hits_equal_up_to_ties(got, gpu_ctx.intersect(o, d), "1M random") == 0
     assert np.array_equal(got_s[0] >= 0, gpu_ctx.intersect(so, sd, sh, tm)[0] >= 0)
     gpu_ctx.accum_clear()

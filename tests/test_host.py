@@ -597,10 +597,22 @@ def test_sah_build(hp, name):
     common/BVH.hpp:28): a valid two-level tree over the same triangle records with a lower surface-area cost than the
     reference's median splits, a traversal stack no deeper than log2 of the triangle count, the emitting mesh's
     subtree (which Scene::sampleLight descends) and all light tables untouched; deterministic."""
-    ref = hp.Scene.CreateNamedScene(name, 5, 64, 64)
+    ref = hp.Scene.CreateNamedScene(name, 5, 64, 64, bvh_build=hp.BVH_BUILD_HOST)
     sah = hp.Scene.CreateNamedScene(name, 5, 64, 64, bvh_build=hp.BVH_BUILD_SAH)
     assert ref.bvh_build == hp.BVH_BUILD_HOST and sah.bvh_build == hp.BVH_BUILD_SAH and not sah.gpu_build
     fr, fs = ref.flat_arrays(), sah.flat_arrays()
+    # the default ("auto") picks the surface-area tree for scenes of more than 64 primitives, the reference's below
+    auto = hp.Scene.CreateNamedScene(name, 5, 64, 64, bvh_build=hp.BVH_BUILD_AUTO)
+    assert auto.bvh_build == (hp.BVH_BUILD_SAH if len(fr["tris"]) > 64 else hp.BVH_BUILD_HOST)
+    assert hp.Scene.CreateBuiltinScene(hp.Scene.CornellBox, 5).bvh_build == hp.BVH_BUILD_HOST
+    # the reference's own tree rides along for the rays with a zero direction component (hpt_scene_desc::ref_nodes):
+    # bit for bit the node array of the reference build (leaf words index the same triangle records)
+    assert fr["ref_nodes"] is None
+    assert np.array_equal(fs["ref_nodes"].view(np.uint32), fr["nodes"].view(np.uint32))
+    # and the trees the Scene shows its callers (Scene::bvh, Scene::mesh_bvhs) are the reference's either way
+    for mesh in (-1, 0, len(fr["lights"])):
+        dr, ds = ref.bvh_dump(mesh), sah.bvh_dump(mesh)
+        assert all(np.array_equal(dr[k], ds[k]) for k in dr)
     cost_r, need_r, leaves_r = _tree_facts(fr)
     cost_s, need_s, leaves_s = _tree_facts(fs)
     nt = len(fr["tris"])
