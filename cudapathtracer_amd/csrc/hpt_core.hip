@@ -706,7 +706,9 @@ __device__ __forceinline__ void schedule_wave(const DevScene& S, const float4* l
         } else if (what == 1) {
             // rounds of box steps while enough lanes take part
             do {
-                if (st == kLaneWalk && Trav::can_step(W)) Trav::step(S, lds, tq, W COUNT_PASS);
+                const bool stepping = st == kLaneWalk && Trav::can_step(W);
+                Trav::fetch(S, lds, tq, W, stepping);  // every lane of the wave (the cooperative record fetch; nothing otherwise)
+                if (stepping) Trav::step(S, lds, tq, W COUNT_PASS);
             } while ((uint32_t)__popcll(__ballot(st == kLaneWalk && Trav::can_step(W))) >= HPT_SM_T_STEP);
         } else if (what == 2) {
             // rounds of triangle tests: every lane that has a triangle to test takes part (also lanes
@@ -847,51 +849,31 @@ k_wf_bounces_sm(DevScene S, int max_depth, uint32_t seg, WfQueue q0, WfQueue q1,
 }
 
 // ---- single-kernel mode under the scheduler ----
-// The work pool of k_render_mega (units of (8x8 pixel tile, s_chunk samples) drawn from a global counter,
-// two units in flight per wave, one 64-pixel accumulator in LDS per unit) as the scheduler's source of paths.
+// The work pool of k_render_mega (units of (8x8 pixel tile, s_chunk samples) drawn from a global counter) as the
+// scheduler's source of paths.  A finished path adds its radiance to its pixel with 64-bit global atomics, as the
+// streamed mode does: the per-tile accumulators k_render_mega keeps in LDS (3 KiB per wave) would cost these
+// kernels, whose per-lane stacks and queues fill the LDS, a workgroup per compute unit (1.0 M-triangle height
+// field: three workgroups instead of four), and the atomics are few next to the record fetches of such scenes.
 struct MegaPolicy {
     const DevScene& S;
     uint32_t s_begin_all, s_count_all, s_chunk, n_units;
-    unsigned long long* out;
+    int64_t* accum;
     unsigned long long* stats;
     uint32_t* unit_counter;
-    unsigned long long* tile_acc;
     uint32_t lane, wave_lanes, W, H, tiles_x, n_tiles;
-    // wave-uniform unit state: the unit whose pool is being handed out, and the one before it
+    // wave-uniform: the unit whose pool is being handed out
     uint32_t cur_x0 = 0, cur_y0 = 0, cur_vw = 1, cur_nv = 0, cur_s0 = 0, cur_total = 0, cur_next = 0;
-    uint32_t old_x0 = 0, old_y0 = 0, old_vw = 1, old_nv = 0;
-    bool cur_open = false, old_open = false, queue_empty = false;
-    uint32_t gen = 0;  // accumulator of `cur`; `old` uses the other one
+    bool cur_open = false, queue_empty = false;
     // per lane
-    uint32_t n_closest = 0, n_shadow = 0, n_paths_wave = 0, slot = 0, lane_gen = 0;
+    uint32_t n_closest = 0, n_shadow = 0, n_paths_wave = 0;
 
-    __device__ __forceinline__ void flush(unsigned long long* acc, uint32_t x0, uint32_t y0, uint32_t vw, uint32_t nv) {
-        for (uint32_t j = lane; j < nv; j += wave_lanes) {
-            const unsigned long long pix = (unsigned long long)(y0 + j / vw) * W + x0 + j % vw;
-            for (uint32_t c = 0; c < 3u; ++c) {
-                const unsigned long long v = acc[3u * j + c];
-                if (v) atomicAdd(out + 3ull * pix + c, v);
-                acc[3u * j + c] = 0ull;
-            }
-        }
-    }
     __device__ __forceinline__ bool pool_has_items() const { return cur_open && cur_next < cur_total; }
-    // idle lanes can be served from the open pool, or from the next unit once the unit before the current
-    // one has no path in flight any more (its accumulator is needed for the new unit)
-    __device__ __forceinline__ uint32_t refillable(unsigned long long m_idle, unsigned long long m_busy) {
-        if (pool_has_items()) return (uint32_t)__popcll(m_idle);
-        if (queue_empty) return 0u;
-        const bool old_busy = old_open && __ballot(lane_gen != gen) & m_busy;
-        return old_busy ? 0u : (uint32_t)__popcll(m_idle);
+    __device__ __forceinline__ uint32_t refillable(unsigned long long m_idle, unsigned long long) const {
+        return (pool_has_items() || !queue_empty) ? (uint32_t)__popcll(m_idle) : 0u;
     }
     __device__ __forceinline__ void refill(bool idle, Path& p, bool& got) {
         const unsigned long long need = __ballot(idle);
         if (!pool_has_items() && !queue_empty) {
-            // pool exhausted (and `old` has drained, see refillable): retire `old`, open the next unit
-            if (old_open) {
-                flush(tile_acc + (gen ^ 1u) * 192u, old_x0, old_y0, old_vw, old_nv);
-                old_open = false;
-            }
             uint32_t u = 0;
             if (lane == 0) u = atomicAdd(unit_counter, 1u);
             u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u);
@@ -901,12 +883,6 @@ struct MegaPolicy {
                 stat_add(stats + kStatClosest, n_closest);
                 stat_add(stats + kStatShadow, n_shadow);
                 n_closest = n_shadow = 0;
-                old_x0 = cur_x0;
-                old_y0 = cur_y0;
-                old_vw = cur_vw;
-                old_nv = cur_nv;
-                old_open = cur_open;
-                gen ^= 1u;
                 const uint32_t tile = u % n_tiles, chunk = u / n_tiles;
                 cur_x0 = (tile % tiles_x) * 8u;
                 cur_y0 = (tile / tiles_x) * 8u;
@@ -925,7 +901,7 @@ struct MegaPolicy {
             const uint32_t k = cur_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
             cur_next = min(cur_total, cur_next + (uint32_t)__popcll(need));
             if (idle && k < cur_total) {
-                uint32_t px, py, smp;
+                uint32_t slot, px, py, smp;
                 if (cur_nv == 64u) {  // full tile (wave-uniform): no integer divisions
                     slot = k & 63u;
                     smp = k >> 6;
@@ -938,23 +914,15 @@ struct MegaPolicy {
                     py = slot / cur_vw;
                 }
                 generate_camera_path(S, (cur_y0 + py) * W + cur_x0 + px, cur_s0 + smp, p);
-                lane_gen = gen;
                 got = true;
             }
         }
     }
     __device__ __forceinline__ void count_closest() { ++n_closest; }
     __device__ __forceinline__ void count_shadow() { ++n_shadow; }
-    __device__ __forceinline__ void finish(const Path& p) {
-        unsigned long long* acc = tile_acc + lane_gen * 192u + 3u * slot;
-        atomicAdd(acc + 0u, (unsigned long long)radiance_to_fixed(p.rad.x));
-        atomicAdd(acc + 1u, (unsigned long long)radiance_to_fixed(p.rad.y));
-        atomicAdd(acc + 2u, (unsigned long long)radiance_to_fixed(p.rad.z));
-    }
+    __device__ __forceinline__ void finish(const Path& p) { accumulate_pixel(accum, p.pixel, p.rad); }
     __device__ __forceinline__ bool next_bounce(bool keep, const Path&) const { return keep; }  // the lane keeps its path
     __device__ __forceinline__ void close() {
-        if (old_open) flush(tile_acc + (gen ^ 1u) * 192u, old_x0, old_y0, old_vw, old_nv);
-        if (cur_open) flush(tile_acc + gen * 192u, cur_x0, cur_y0, cur_vw, cur_nv);
         stat_add(stats + kStatClosest, n_closest);
         stat_add(stats + kStatShadow, n_shadow);
         stat_add(stats + kStatPaths, lane == 0 ? n_paths_wave : 0u);
@@ -970,17 +938,12 @@ k_render_mega_sm(DevScene S, int max_depth, uint32_t s_begin_all, uint32_t s_cou
                  int64_t* __restrict__ accum, unsigned long long* __restrict__ stats, uint32_t* __restrict__ unit_counter) {
     extern __shared__ float4 lds[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t waves_per_block = (blockDim.x + 63u) >> 6;
     const uint32_t wave_lanes = min(64u, blockDim.x - wave * 64u);  // the last wave of an odd-sized block is partial
-    // two accumulators (unit generations 0 / 1) of 64 pixels x RGB per wave
-    unsigned long long* tile_acc = reinterpret_cast<unsigned long long*>(lds + S.lds_float4s) + wave * 384u;
-    for (uint32_t i = lane; i < 384u; i += wave_lanes) tile_acc[i] = 0ull;
-    const TriQueue tq = make_tri_queue<kScene>(reinterpret_cast<uint32_t*>(lds + S.lds_float4s) + waves_per_block * 768u);
+    const TriQueue tq = make_tri_queue<kScene>(reinterpret_cast<uint32_t*>(lds + S.lds_float4s));
     stage_scene<kScene>(S, lds);
     const uint32_t W = (uint32_t)S.width, H = (uint32_t)S.height;
     const uint32_t tiles_x = (W + 7u) >> 3;
-    MegaPolicy pol{S, s_begin_all, s_count_all, s_chunk, n_units, reinterpret_cast<unsigned long long*>(accum), stats, unit_counter,
-                   tile_acc, lane, wave_lanes, W, H, tiles_x, tiles_x * ((H + 7u) >> 3)};
+    MegaPolicy pol{S, s_begin_all, s_count_all, s_chunk, n_units, accum, stats, unit_counter, lane, wave_lanes, W, H, tiles_x, tiles_x * ((H + 7u) >> 3)};
     COUNT_DECL;
     schedule_wave<kScene, kExt>(S, lds, tq, max_depth, pol COUNT_PASS);
     pol.close();
@@ -1514,7 +1477,8 @@ int settle_events(hpt_ctx* ctx, bool wait) {
 uint32_t lds_bytes(const DevScene& S, int block) {
     const bool pair = S.variant == kScenePair || S.variant == kScenePairLds || S.variant == kScenePairCull;
     const bool queue = pair || S.variant == kSceneGlobal || S.variant == kSceneLds;
-    return S.lds_float4s * 16u + (queue ? (uint32_t)block * tri_queue_entries(S.variant) * 4u : 0u) + (pair ? (uint32_t)block * S.stack_depth * 4u : 0u);
+    const uint32_t staging = coop_variant(S.variant) ? (((uint32_t)block + 63u) >> 6) * kCoopWaveBytes : 0u;  // cooperative record fetch
+    return S.lds_float4s * 16u + staging + (queue ? (uint32_t)block * tri_queue_entries(S.variant) * 4u : 0u) + (pair ? (uint32_t)block * S.stack_depth * 4u : 0u);
 }
 
 int grid_for(const hpt_ctx* ctx, uint64_t work, int block) {
@@ -1655,8 +1619,8 @@ int render_launch(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sam
         const char* sched_mask = getenv("HPT_MEGA_SCHEDULER_VARIANTS");
         const uint32_t mega_mask = sched_mask ? (uint32_t)strtoul(sched_mask, nullptr, 0) : kMegaSchedulerVariants;
         const bool scheduler = has_scheduler(S.variant) && !(sched_env && atoi(sched_env) == 0) && ((mega_mask >> S.variant) & 1u);
-        // + two tile accumulators per wave + queues; the lock-step kernel also keeps its ring of camera directions there
-        uint32_t lds_mega = lds + waves_per_block * (384u * 8u + (scheduler ? 0u : kCamRingWords * 4u)) + (lds_bytes(S, block) - lds);
+        // + queues; the lock-step kernel also keeps two tile accumulators per wave and its ring of camera directions there
+        uint32_t lds_mega = lds + (scheduler ? 0u : waves_per_block * (384u * 8u + kCamRingWords * 4u)) + (lds_bytes(S, block) - lds);
 #ifdef HPT_PROFILE
         lds_mega += waves_per_block * 3u * kProfSections * 8u;
 #endif

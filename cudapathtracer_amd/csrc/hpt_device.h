@@ -618,11 +618,28 @@ struct TriQueue {
     uint32_t* q;
     uint32_t stride;
     uint32_t* stk;  // traversal stack of the pair variants: entry k of a lane at stk[k * stride]
+    uint32_t stage; // cooperative record fetch (coop_fetch below): LDS byte address of this wave's staging area
 };
-// the per-lane LDS scratch of a workgroup starts at `base` (queues of all lanes, then stacks)
+// Cooperative record fetch (scenes whose records do not fit the L2s).  A lane that fetches its own 64-byte record
+// issues four 16-byte loads to one cache line; a wave does that for 64 different lines, and the three loads that
+// follow a line's first find its miss still in flight.  Here the four lanes of a quad fetch the four pieces of ONE
+// record per instruction (one 64-byte access per quad), straight into LDS (the load's LDS address is wave base +
+// lane * 16), in four instructions for the records of quad-lanes 0..3; each lane then reads its record back.
+// Piece k of the wave lies at byte kCoopPieceBytes * k: 1024 + 16, so that the lanes of a read hit different banks.
+#ifndef HPT_COOP
+#define HPT_COOP 0
+#endif
+constexpr uint32_t kCoopPieceBytes = 1040u, kCoopWaveBytes = 4u * kCoopPieceBytes;
+__host__ __device__ constexpr bool coop_variant(int scene) { return HPT_COOP != 0 && scene == 5; }
+// the per-lane LDS scratch of a workgroup starts at `base`: (staging areas of all waves,) queues of all lanes, then stacks
 template <int kScene>
 HD TriQueue make_tri_queue(uint32_t* base) {
-    return TriQueue{base + threadIdx.x, blockDim.x, base + tri_queue_entries(kScene) * blockDim.x + threadIdx.x};
+    uint32_t stage = 0u;
+    if constexpr (coop_variant(kScene)) {
+        stage = lds_address(base) + (threadIdx.x >> 6) * kCoopWaveBytes;
+        base += ((blockDim.x + 63u) >> 6) * (kCoopWaveBytes / 4u);
+    }
+    return TriQueue{base + threadIdx.x, blockDim.x, base + tri_queue_entries(kScene) * blockDim.x + threadIdx.x, stage};
 }
 
 template <int kScene, bool kShadow>
@@ -995,13 +1012,49 @@ HD void walk_begin(const DevScene& S, Walk& W, f3 o, f3 d, bool shadow, float tm
 // visit record W.cur (requires walk_can_step): test both children's boxes, queue the leaves that
 // are hit, descend into / push the interior children that are hit, else pop
 template <int kScene>
+HD void walk_step_record(const DevScene& S, const float4 q0, const float4 q1, const float4 q2, const float4 q3, TriQueue tq, Walk& W COUNT_ARG);
+template <int kScene>
 HD void walk_step(const DevScene& S, const float4* __restrict__ N, TriQueue tq, Walk& W COUNT_ARG) {
+    const float4 q0 = N[4 * W.cur], q1 = N[4 * W.cur + 1], q2 = N[4 * W.cur + 2], q3 = N[4 * W.cur + 3];
+    walk_step_record<kScene>(S, q0, q1, q2, q3, tq, W COUNT_PASS);
+}
+// Wave-level half of a cooperative step: every lane of the wave calls it (lanes that do not step pass record -1).
+HD int quad_lane_value(int v, int k) {
+    switch (k) {  // DPP quad_perm broadcast of quad-lane k; a lane that does not exist reads as -1
+    case 0: return __builtin_amdgcn_update_dpp(-1, v, 0x00, 0xF, 0xF, false);
+    case 1: return __builtin_amdgcn_update_dpp(-1, v, 0x55, 0xF, 0xF, false);
+    case 2: return __builtin_amdgcn_update_dpp(-1, v, 0xAA, 0xF, 0xF, false);
+    default: return __builtin_amdgcn_update_dpp(-1, v, 0xFF, 0xF, 0xF, false);
+    }
+}
+HD void coop_fetch(const float4* __restrict__ N, TriQueue tq, int record) {
+    const uint32_t piece = threadIdx.x & 3u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = quad_lane_value(record, k);
+        if (r >= 0) {
+            const float4* src = N + 4 * (size_t)r + piece;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(uintptr_t)(tq.stage + (uint32_t)k * kCoopPieceBytes), 16, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+// Lane-level half: the record this lane asked for, read back from the staging area
+template <int kScene>
+HD void walk_step_staged(const DevScene& S, TriQueue tq, Walk& W COUNT_ARG) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t at = tq.stage + (lane & 3u) * kCoopPieceBytes + (lane & ~3u) * 16u;
+    const float4 q0 = lds_read(at), q1 = lds_read(at + 16u), q2 = lds_read(at + 32u), q3 = lds_read(at + 48u);
+    walk_step_record<kScene>(S, q0, q1, q2, q3, tq, W COUNT_PASS);
+}
+template <int kScene>
+HD void walk_step_record(const DevScene& S, const float4 q0, const float4 q1, const float4 q2, const float4 q3, TriQueue tq, Walk& W COUNT_ARG) {
     constexpr bool kCull = (kScene == kScenePairCull);
     const bool cull = kCull && W.finite;
     const float behind = -S.cull_slack;
     const f3 o = W.o, inv = W.inv;
     COUNT_BOX(2);
-    const float4 q0 = N[4 * W.cur], q1 = N[4 * W.cur + 1], q2 = N[4 * W.cur + 2], q3 = N[4 * W.cur + 3];
     bool hl, hr;
     float tnl = 0.f, tnr = 0.f;
     if (cull) {
@@ -1124,7 +1177,15 @@ struct PairTraversal {
     HD static bool wants_test(const State& W) { return !walk_can_step<kScene>(W) && W.cnt > 0u; }
     HD static bool may_test(const State& W) { return W.cnt > 0u; }
     HD static bool done(const State& W) { return walk_done(W); }
-    HD static void step(const DevScene& S, const float4* lds, TriQueue tq, State& W COUNT_ARG) { walk_step<kScene>(S, records(S, lds), tq, W COUNT_PASS); }
+    // A round of steps: `fetch` is called by EVERY lane of the wave (stepping = this lane takes part), then `step` by the
+    // lanes that take part.  Only the cooperative record fetch does anything in `fetch`.
+    HD static void fetch(const DevScene& S, const float4* lds, TriQueue tq, const State& W, bool stepping) {
+        if constexpr (coop_variant(kScene)) coop_fetch(S.pairs, tq, stepping ? W.cur : -1);
+    }
+    HD static void step(const DevScene& S, const float4* lds, TriQueue tq, State& W COUNT_ARG) {
+        if constexpr (coop_variant(kScene)) walk_step_staged<kScene>(S, tq, W COUNT_PASS);
+        else walk_step<kScene>(S, records(S, lds), tq, W COUNT_PASS);
+    }
     HD static void test_one(const DevScene& S, const float4* lds, TriQueue tq, State& W COUNT_ARG) {
         walk_test_one<kScene>(S, triangles(S, lds), tq, W COUNT_PASS);
     }
@@ -1168,6 +1229,7 @@ struct MarkTraversal {
             W.stop = W.at + copy_bytes;
         }
     }
+    HD static void fetch(const DevScene&, const float4*, TriQueue, const State&, bool) {}
     HD static bool can_step(const State& W) { return W.at < W.stop; }
     HD static bool wants_test(const State& W) { return W.at >= W.stop && W.pending != 0; }
     HD static bool may_test(const State& W) { return W.at >= W.stop && W.filtered && W.pending != 0; }
