@@ -502,6 +502,42 @@ HD bool tri_hit(const float4* __restrict__ T, int tri, f3 o, f3 d, double& t_out
     return true;
 }
 
+// The same test on a record that has been read already, without early exits.  The walks that read their
+// records through L1/L2 use this form: tri_hit's staged exits make four DEPENDENT fetches of one 64-byte record
+// (flag word, normal, e1/e2, v0: each waits for the one before), and a wave runs the whole test anyway while any
+// of its lanes goes on.  Every comparison is the reference's, in its order and with its NaN behaviour (a NaN passes
+// `u < 0 || u > 1` there too); a stage that has failed only keeps later stages from mattering.
+HD bool tri_hit_record(const float4 r0, const float4 r1, const float4 r2, const float4 r3, f3 o, f3 d, double& t_out) {
+    if (__float_as_uint(r3.w) & kSphereBit) {  // Sphere::getIntersection on (center, radius^2)
+        const f3 L = o - xyz(r0);
+        const float a = dot(d, d);
+        const float b = 2 * dot(d, L);
+        const float c = dot(L, L) - r1.y;
+        float t0, t1;
+        if (!solveQuadratic(a, b, c, t0, t1)) return false;
+        if (t0 < 0) t0 = t1;
+        if (t0 < 0) return false;
+        t_out = (double)t0;
+        return true;
+    }
+    const f3 v0 = xyz(r0), e1 = xyz(r1), e2 = xyz(r2), n = xyz(r3);
+    bool ok = !(dot(d, n) > 0);
+    const f3 pvec = cross(d, e2);
+    const float detf = dot(e1, pvec);
+    ok = ok && !(fabsf(detf) < kEpsilon5);
+    const double det_inv = reciprocal_of_float(ok ? detf : 1.0f);
+    const f3 tvec = o - v0;
+    const double u = (double)dot(tvec, pvec) * det_inv;
+    ok = ok && !(u < 0 || u > 1);
+    const f3 qvec = cross(tvec, e1);
+    const double v = (double)dot(d, qvec) * det_inv;
+    ok = ok && !(v < 0 || u + v > 1);
+    const double t = (double)dot(e2, qvec) * det_inv;
+    ok = ok && !(t < 0);
+    t_out = t;
+    return ok;
+}
+
 // ---- the same test with the double division taken out of the common case ------------------
 // Triangle::getIntersection decides with u = un * (1/det), v = vn * (1/det), t = tn * (1/det)
 // (un, vn, tn, det: the four float dot products; the products and 1/det in double).  For
@@ -881,7 +917,8 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
                 const int tri = (int)tq.q[k * tq.stride];
                 double t;
                 COUNT_TRI(1);
-                if (tri_hit(T, tri, o, d, t)) {
+                const float4 r0 = T[4 * tri], r1 = T[4 * tri + 1], r2 = T[4 * tri + 2], r3 = T[4 * tri + 3];  // one fetch of the whole record
+                if (tri_hit_record(r0, r1, r2, r3, o, d, t)) {
                     if constexpr (kShadow) {
                         if (t < limit) {
                             best = tri;
@@ -934,7 +971,8 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
                 const int tri = (int)tq.q[k * tq.stride];
                 double t;
                 COUNT_TRI(1);
-                if (tri_hit(T, tri, o, d, t)) {
+                const float4 r0 = T[4 * tri], r1 = T[4 * tri + 1], r2 = T[4 * tri + 2], r3 = T[4 * tri + 3];  // one fetch of the whole record
+                if (tri_hit_record(r0, r1, r2, r3, o, d, t)) {
                     if constexpr (kShadow) {
                         if (t < limit) {
                             best = tri;
@@ -1118,7 +1156,8 @@ HD void walk_test_one(const DevScene& S, const float4* __restrict__ T, TriQueue 
     const int tri = (int)tq.q[W.cnt * tq.stride];
     double t;
     COUNT_TRI(1);
-    if (tri_hit(T, tri, W.o, W.d, t)) {
+    const float4 r0 = T[4 * tri], r1 = T[4 * tri + 1], r2 = T[4 * tri + 2], r3 = T[4 * tri + 3];  // one fetch of the whole record
+    if (tri_hit_record(r0, r1, r2, r3, W.o, W.d, t)) {
         if (W.shadow) {
             if (t < (double)W.tmax - (double)kEpsilon4) {  // BVH.hpp:121-127: occluded, the query ends
                 W.best = tri;
