@@ -663,6 +663,7 @@ __device__ __forceinline__ void schedule_wave(const DevScene& S, const float4* l
     using Trav = Traversal<kScene>;
     typename Trav::State W;
     Trav::init(W);
+    const ShadeSrc src = shade_source<kScene, kExt>(S, lds);
     int st = kLaneIdle;
     Path p;
     int hit_tri = -1;
@@ -720,7 +721,7 @@ __device__ __forceinline__ void schedule_wave(const DevScene& S, const float4* l
             if (st == kLaneShadeA) {
                 f3 so, wi;
                 float tmax;
-                const int rc = shade_a<kExt>(S, p, hit_tri, hit_t, so, wi, tmax, ls);
+                const int rc = shade_a<kExt>(S, src, p, hit_tri, hit_t, so, wi, tmax, ls);
                 if (rc == kShadeMiss) {
                     pol.finish(p);
                     st = kLaneIdle;
@@ -738,7 +739,7 @@ __device__ __forceinline__ void schedule_wave(const DevScene& S, const float4* l
             bool keep = false;
             const bool shading = st == kLaneShadeB;
             if (shading) {
-                shade_b<kExt>(S, p, hit_tri, hit_t, lit && W.best < 0, W.d, ls);
+                shade_b<kExt>(S, src, p, hit_tri, hit_t, lit && W.best < 0, W.d, ls);
                 keep = p.depth < max_depth;
                 if (!keep) pol.finish(p);
                 st = kLaneIdle;
@@ -1020,6 +1021,7 @@ struct hpt_ctx {
     float4* d_tri_v12 = nullptr;
     float4* d_pairs = nullptr;
     float4* d_ref_nodes = nullptr;  // the reference's tree beside the caller's (threaded walk through L1/L2 only)
+    float4* d_fast_light = nullptr; // DevScene::fast_light
     float4* d_oct_nodes = nullptr;
     uint32_t* d_oct_table = nullptr;
     DevMaterial* d_mats = nullptr;
@@ -1067,6 +1069,8 @@ void free_scene(hpt_ctx* ctx) {
     (void)hipFree(ctx->d_pairs);
     (void)hipFree(ctx->d_ref_nodes);
     ctx->d_ref_nodes = nullptr;
+    (void)hipFree(ctx->d_fast_light);
+    ctx->d_fast_light = nullptr;
     (void)hipFree(ctx->d_oct_nodes);
     (void)hipFree(ctx->d_oct_table);
     (void)hipFree(ctx->d_mats);
@@ -1605,7 +1609,7 @@ int render_launch(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sam
     // box), so small workgroups leave most of a CU's wave slots empty (64 lanes: half the speed of
     // 256).  No result depends on the workgroup size, so such scenes are run with at least 256
     // lanes per workgroup; HPT_EXACT_BLOCK=1 keeps the size asked for.
-    if (S.lds_float4s > 0 && block < 256) {
+    if (S.mat_lds_off > 0 && block < 256) {
         const char* e = getenv("HPT_EXACT_BLOCK");
         if (!(e && atoi(e) != 0)) block = 256;
     }
@@ -1911,7 +1915,8 @@ int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* sc) {
         }
         ctx->has_sphere = has_sphere;
         HIP_TRY(hipMemcpy(ctx->d_mats, mats.data(), mats.size() * sizeof(DevMaterial), hipMemcpyHostToDevice));
-        ctx->scene_extended = glass || has_sphere;
+        // (kernels built without kExt read their materials from LDS: scenes with more materials than fit there take the others)
+        ctx->scene_extended = glass || has_sphere || sc->num_materials > kMaxLdsMaterials;
         ctx->extended = ctx->scene_extended || ctx->integrator != 0;
         HIP_TRY(hipMemcpy(ctx->d_lights, lights.data(), lights.size() * sizeof(DevLight), hipMemcpyHostToDevice));
     }
@@ -2120,6 +2125,49 @@ int hpt_scene_upload(hpt_ctx* ctx, const hpt_scene_desc* sc) {
     case kSceneTiny64: S.lds_float4s = (uint32_t)f4_tiny; break;
     case kScenePairLds: S.lds_float4s = (uint32_t)f4_pair; break;
     default: S.lds_float4s = 0u; break;
+    }
+    // the materials ride behind the staged scene (or alone) in every workgroup's LDS when they are few
+    S.mat_lds_off = S.lds_float4s;
+    S.mat_lds_float4s = sc->num_materials <= kMaxLdsMaterials ? 2u * sc->num_materials * (uint32_t)(sizeof(DevMaterial) / 16u) : 0u;
+    S.lds_float4s += S.mat_lds_float4s;
+    // DevScene::fast_light: one light whose mesh tree is a root over two leaves
+    if (sc->num_lights == 1) {
+        const hpt_light& l = sc->lights[0];
+        auto word = [&](size_t node, int w) {
+            int32_t v;
+            std::memcpy(&v, &sc->nodes[8 * node + w], 4);
+            return v;
+        };
+        const size_t root = l.root_node;
+        const char* e = getenv("HPT_FAST_LIGHT");  // 0: the general light-sampling code (A/B runs, tests)
+        if (word(root, 7) < 0 && root + 2 < (size_t)sc->num_nodes + 0u && !(e && atoi(e) == 0)) {
+            const size_t left = root + 1, right = (size_t)word(left, 3);
+            if (right < sc->num_nodes && word(left, 7) >= 0 && word(right, 7) >= 0) {
+                float f[4 * kFastLightFloat4s] = {};
+                const int32_t t2[2] = {word(left, 7), word(right, 7)};
+                for (int k = 0; k < 2; ++k) {
+                    const float* r = &tris[16 * (size_t)t2[k]];  // the device copy's values (word 3 = MIS light pdf)
+                    const float* v = &sc->tri_v12[8 * (size_t)t2[k]];
+                    for (int c = 0; c < 3; ++c) {
+                        f[16 * k + c] = r[c];
+                        f[16 * k + 4 + c] = v[c];
+                        f[16 * k + 8 + c] = v[4 + c];
+                        f[16 * k + 12 + c] = r[12 + c];
+                    }
+                    f[16 * k + 3] = r[3];
+                }
+                f[32] = l.area;
+                f[33] = l.root_area;
+                f[34] = 1.0f / l.root_area;
+                f[35] = sc->node_area[left];
+                for (int c = 0; c < 3; ++c) f[36 + c] = sc->materials[l.material].emission[c];
+                ALLOC_TRY(ctx->d_fast_light, sizeof f, "fast_light");
+                HIP_TRY(hipMemcpy(ctx->d_fast_light, f, sizeof f, hipMemcpyHostToDevice));
+                S.fast_light = ctx->d_fast_light;
+                S.light_lds_off = S.lds_float4s;
+                S.lds_float4s += kFastLightFloat4s;
+            }
+        }
     }
     ctx->has_scene = true;
     return HPT_OK;

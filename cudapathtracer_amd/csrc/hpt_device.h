@@ -303,7 +303,23 @@ struct DevScene {
     // the threaded walk of kSceneGlobal reads `ref_nodes` (= `nodes` when there is one tree only).
     uint32_t ref_root, num_ref_nodes;
     const float4* ref_nodes;
+    // Materials staged in LDS by stage_scene (every variant): mat_lds_float4s float4 (both material tables) at float4
+    // offset mat_lds_off of the workgroup's dynamic LDS, counted in lds_float4s.  0 = not staged (more than
+    // kMaxLdsMaterials materials): such scenes run the kernels built with kExt, which read `mats`.
+    uint32_t mat_lds_off, mat_lds_float4s;
+    // The scene's only light when it is one mesh of two triangles (the Cornell light and every scene built on it): all
+    // that Scene::sampleLight and the direct-light term read of it, in ten float4 that stage_scene puts into LDS at
+    // float4 offset light_lds_off (counted in lds_float4s):
+    //   [4k + 0..3], k = 0 left leaf's triangle, 1 right leaf's:  v0.xyz, MIS light pdf | v1.xyz | v2.xyz | normal.xyz
+    //   [8] mesh area, root area, 1 / root area, area of the left leaf      [9] emission.xyz
+    // The values are the ones `lights`, `nodes`, `node_area`, `tris` and `tri_v12` hold (same bits), so taking them from
+    // here changes no result; it saves the chain of dependent fetches the general descent makes per bounce.
+    // fast_light = null: the general code.  (Not kernel arguments: thirty more live scalar registers spilled.)
+    const float4* fast_light;
+    uint32_t light_lds_off;
 };
+constexpr uint32_t kFastLightFloat4s = 10;
+constexpr uint32_t kMaxLdsMaterials = 16;
 enum : uint32_t { kIntegratorRoulette = 1u, kIntegratorRegularize = 2u };
 // word 15 of a record of the triangle array with this bit set: the record is a sphere
 //   center.xyz, 0 | radius, radius^2, 0, bits(material) | 0, 0, 0, bits(prim id) | 0, 0, 0, bits(mesh | kSphereBit)
@@ -344,6 +360,12 @@ HD float4 lds_read(uint32_t at) {
 // workgroup must call it; it ends with a workgroup barrier (also for the variants that stage nothing).
 template <int kScene>
 HD void stage_scene(const DevScene& S, float4* lds) {
+    {
+        const float4* src = reinterpret_cast<const float4*>(S.mats);
+        for (uint32_t i = threadIdx.x; i < S.mat_lds_float4s; i += blockDim.x) lds[S.mat_lds_off + i] = src[i];
+        if (S.fast_light)
+            for (uint32_t i = threadIdx.x; i < kFastLightFloat4s; i += blockDim.x) lds[S.light_lds_off + i] = S.fast_light[i];
+    }
     if constexpr (kScene == kSceneGlobal || kScene == kScenePair || kScene == kScenePairCull) {
         __syncthreads();
     } else if constexpr (kScene == kScenePairLds) {
@@ -1545,19 +1567,111 @@ HD f3 mat_sample(const DevMaterial& m, float r0, float r1, float r2, f3 ray_out_
 // Material and shading normal of a hit.  kExt: the table of regularised materials serves a path
 // that has left a non-specular surface behind when the integrator regularises (Scene.hpp:186-189);
 // a sphere's normal is normalize(coords - center) (Sphere.hpp:62).
+// Where the shading reads the hit triangle's record and the materials: the copies in LDS where a kernel has them
+// (triangle records: the variants that stage their scene; materials: the kernels built without kExt, whose scenes have
+// at most kMaxLdsMaterials materials), the device arrays otherwise.  Same bits either way.
+struct ShadeSrc {
+    const float4* T;
+    const DevMaterial* M;
+    const float4* L;  // DevScene::fast_light's copy in LDS, or null
+};
+template <int kScene, bool kExt>
+HD ShadeSrc shade_source(const DevScene& S, const float4* lds) {
+    ShadeSrc src;
+#ifndef HPT_SHADE_T_GLOBAL
+#define HPT_SHADE_T_GLOBAL 0
+#endif
+#ifndef HPT_SHADE_M_GLOBAL
+#define HPT_SHADE_M_GLOBAL 0
+#endif
+    constexpr bool kTiny = kScene == kSceneTiny32 || kScene == kSceneTiny64;
+    if constexpr (kScene == kScenePairLds) src.T = lds + 4u * S.num_pairs;
+    else if constexpr (kScene == kSceneLds) src.T = lds + 2u * S.num_nodes;
+    else if constexpr (kTiny && !HPT_SHADE_T_GLOBAL) src.T = lds + 18u * S.num_nodes;
+    else src.T = S.tris;
+    if constexpr (kTiny && HPT_SHADE_M_GLOBAL) src.M = S.mats;
+    else if constexpr (kExt) src.M = S.mat_lds_float4s ? reinterpret_cast<const DevMaterial*>(lds + S.mat_lds_off) : S.mats;
+    else src.M = reinterpret_cast<const DevMaterial*>(lds + S.mat_lds_off);
+    src.L = S.fast_light ? lds + S.light_lds_off : nullptr;
+    return src;
+}
+// Scene::sampleLight (common/Scene.hpp:99-120) with BVHAccel::Sample / getSample (common/BVH.hpp:147-184) and
+// Triangle::Sample (common/Triangle.hpp:75-82): the sampled point, its normal, the triangle's MIS light pdf, the
+// sampling pdf (0 = no light chosen) and the light's index, from the four draws of one Philox block.
+struct LightPoint {
+    f3 x, n;
+    float lightPdf, lightSamplePdf;
+    uint32_t light;
+};
+HD LightPoint sample_light(const DevScene& S, const ShadeSrc& src, const u4 ra) {
+    LightPoint lp;
+    lp.x = lp.n = mk(0.f);
+    lp.lightPdf = lp.lightSamplePdf = 0.0f;
+    lp.light = 0u;
+    const float pick = u01(ra.x) * S.sum_light_area;
+    if (src.L) {  // (wave-uniform) one light of two triangles, staged in LDS
+        const float4 areas = src.L[8];  // mesh area, root area, 1 / root area, left leaf's area
+        const float emit_area_sum = 0.f + areas.x;
+        if (pick <= emit_area_sum) {
+            const float q = sqrt_rn(u01(ra.y)) * areas.y;
+            const float4* tri = src.L + (q < areas.w ? 0 : 4);  // the root's children are leaves: left if q < its area, else right
+            const float sx = sqrt_rn(u01(ra.z)), sy = u01(ra.w);
+            const float4 a0 = tri[0], b1 = tri[1], b2 = tri[2], a3 = tri[3];
+            lp.x = xyz(a0) * (1.0f - sx) + xyz(b1) * (sx * (1.0f - sy)) + xyz(b2) * (sx * sy);
+            lp.n = xyz(a3);
+            lp.lightPdf = a0.w;
+            lp.lightSamplePdf = areas.z;
+        }
+        return lp;
+    }
+    float emit_area_sum = 0;
+    for (uint32_t k = 0; k < S.num_lights; ++k) {
+        const DevLight& L = S.lights[k];
+        emit_area_sum += L.area;
+        if (pick <= emit_area_sum) {
+            float q = sqrt_rn(u01(ra.y)) * L.root_area;
+            uint32_t node = L.root_node;
+            int tri;
+            while ((tri = __float_as_int(S.nodes[2 * node + 1].w)) < 0) {
+                const uint32_t left = node + 1;
+                const float la = S.node_area[left];
+                if (q < la) node = left;
+                else {
+                    q -= la;
+                    node = (uint32_t)__float_as_int(S.nodes[2 * left].w);
+                }
+            }
+            const float sx = sqrt_rn(u01(ra.z)), sy = u01(ra.w);
+            const float4 a0 = S.tris[4 * tri], a3 = S.tris[4 * tri + 3];
+            const float4 b1 = S.tri_v12[2 * tri], b2 = S.tri_v12[2 * tri + 1];
+            lp.x = xyz(a0) * (1.0f - sx) + xyz(b1) * (sx * (1.0f - sy)) + xyz(b2) * (sx * sy);
+            lp.n = xyz(a3);
+            lp.lightPdf = a0.w;
+            lp.lightSamplePdf = L.inv_root_area;
+            lp.light = k;
+            break;
+        }
+    }
+    return lp;
+}
+HD f3 light_emission(const DevScene& S, const ShadeSrc& src, uint32_t light) {
+    if (src.L) return xyz(src.L[9]);
+    const DevLight& L = S.lights[light];
+    return mk(L.emission[0], L.emission[1], L.emission[2]);
+}
 template <bool kExt>
-HD const DevMaterial& hit_material(const DevScene& S, int hit_tri, bool diffused) {
-    uint32_t m = (uint32_t)__float_as_int(S.tris[4 * hit_tri + 1].w);
+HD const DevMaterial& hit_material(const DevScene& S, const ShadeSrc& src, int hit_tri, bool diffused) {
+    uint32_t m = (uint32_t)__float_as_int(src.T[4 * hit_tri + 1].w);
     if constexpr (kExt) {
         if ((S.integrator & kIntegratorRegularize) && diffused) m += S.num_mats;
     }
-    return S.mats[m];
+    return src.M[m];
 }
 template <bool kExt>
-HD f3 hit_normal(const DevScene& S, int hit_tri, f3 coords) {
-    const float4 n4 = S.tris[4 * hit_tri + 3];
+HD f3 hit_normal(const DevScene& S, const ShadeSrc& src, int hit_tri, f3 coords) {
+    const float4 n4 = src.T[4 * hit_tri + 3];
     if constexpr (kExt) {
-        if (S.has_spheres && (__float_as_uint(n4.w) & kSphereBit)) return normalize(coords - xyz(S.tris[4 * hit_tri]));
+        if (S.has_spheres && (__float_as_uint(n4.w) & kSphereBit)) return normalize(coords - xyz(src.T[4 * hit_tri]));
     }
     return xyz(n4);
 }
@@ -1622,6 +1736,7 @@ template <int kScene, bool kExt, uint32_t kShadowInc = 1u>
 HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, Path& p, int hit_tri, double hit_t,
                      uint32_t& shadow_queries PROF_ARG COUNT_ARG) {
     bool alive = true;
+    const ShadeSrc src = shade_source<kScene, kExt>(S, lds);
 #ifdef HPT_PROFILE
     unsigned long long prof_s0 = __builtin_readcyclecounter();
     PROF_ITER(kProfShadeA);
@@ -1631,16 +1746,16 @@ HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, TriQueue
             alive = false;
             break;
         }
-        // the device copies in global memory (not the LDS stage): word 3 = light pdf
+        // (word 3 of a device triangle record = its MIS light pdf, in the LDS copies too)
         const f3 coords = p.o + p.d * (float)hit_t;  // Ray::operator(), Ray.hpp:27
         {
-            const DevMaterial& material = hit_material<kExt>(S, hit_tri, p.diffused);
+            const DevMaterial& material = hit_material<kExt>(S, src, hit_tri, p.diffused);
             if (material.flags & kMatEmitting) {  // :164-184
                 const f3 radiance = mk(material.emission[0], material.emission[1], material.emission[2]);
                 if (p.depth == 0 || p.specular) {
                     p.rad = p.rad + p.thr * radiance;
                 } else {
-                    const float weight = powerHeuristic(p.pdf, S.tris[4 * hit_tri].w);
+                    const float weight = powerHeuristic(p.pdf, src.T[4 * hit_tri].w);
                     p.rad = p.rad + p.thr * radiance * weight;
                 }
             }
@@ -1649,42 +1764,10 @@ HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, TriQueue
         if (!p.specular) {  // :192-228
             // Scene::sampleLight (:99-120)
             const u4 ra = philox4x32_10((uint32_t)p.depth, 0u, S.seed, 0u, p.pixel, p.sample);
-            float lightSamplePdf = 0.0f, lightPdf = 0.0f;
-            f3 lx = mk(0.f), ln = mk(0.f);
-            uint32_t light = 0;
-            {
-                const float pick = u01(ra.x) * S.sum_light_area;
-                float emit_area_sum = 0;
-                for (uint32_t k = 0; k < S.num_lights; ++k) {
-                    const DevLight& L = S.lights[k];
-                    emit_area_sum += L.area;
-                    if (pick <= emit_area_sum) {
-                        // BVHAccel::Sample / getSample (BVH.hpp:147-184)
-                        float q = sqrt_rn(u01(ra.y)) * L.root_area;
-                        uint32_t node = L.root_node;
-                        int tri;
-                        while ((tri = __float_as_int(S.nodes[2 * node + 1].w)) < 0) {
-                            const uint32_t left = node + 1;
-                            const float la = S.node_area[left];
-                            if (q < la) node = left;
-                            else {
-                                q -= la;
-                                node = (uint32_t)__float_as_int(S.nodes[2 * left].w);
-                            }
-                        }
-                        // Triangle::Sample (Triangle.hpp:75-82)
-                        const float sx = sqrt_rn(u01(ra.z)), sy = u01(ra.w);
-                        const float4 a0 = S.tris[4 * tri], a3 = S.tris[4 * tri + 3];
-                        const float4 b1 = S.tri_v12[2 * tri], b2 = S.tri_v12[2 * tri + 1];
-                        lx = xyz(a0) * (1.0f - sx) + xyz(b1) * (sx * (1.0f - sy)) + xyz(b2) * (sx * sy);
-                        ln = xyz(a3);
-                        lightPdf = a0.w;
-                        lightSamplePdf = L.inv_root_area;
-                        light = k;
-                        break;
-                    }
-                }
-            }
+            const LightPoint lp = sample_light(S, src, ra);
+            const float lightSamplePdf = lp.lightSamplePdf, lightPdf = lp.lightPdf;
+            const f3 lx = lp.x, ln = lp.n;
+            uint32_t light = lp.light;
             if (lightSamplePdf > 0.0f) {
                 const f3 px = lx - coords;
                 const f3 wi = normalize(px);
@@ -1707,10 +1790,9 @@ HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, TriQueue
 #endif
                 if (occ_tri < 0) {
                     asm volatile("" : "+v"(hit_tri), "+v"(light));  // forget what was derived from them
-                    const f3 normal = hit_normal<kExt>(S, hit_tri, coords);
-                    const DevMaterial& material = hit_material<kExt>(S, hit_tri, p.diffused);
-                    const DevLight& L = S.lights[light];
-                    const f3 lemit = mk(L.emission[0], L.emission[1], L.emission[2]);
+                    const f3 normal = hit_normal<kExt>(S, src, hit_tri, coords);
+                    const DevMaterial& material = hit_material<kExt>(S, src, hit_tri, p.diffused);
+                    const f3 lemit = light_emission(S, src, light);
                     const f3 wo = -p.d;
                     f3 bsdf;
                     float bsdfPdf;
@@ -1724,8 +1806,8 @@ HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, TriQueue
 
         // :230-250
         asm volatile("" : "+v"(hit_tri));
-        const f3 normal = hit_normal<kExt>(S, hit_tri, coords);
-        const DevMaterial& material = hit_material<kExt>(S, hit_tri, p.diffused);
+        const f3 normal = hit_normal<kExt>(S, src, hit_tri, coords);
+        const DevMaterial& material = hit_material<kExt>(S, src, hit_tri, p.diffused);
         const u4 rb = philox4x32_10((uint32_t)p.depth, 1u, S.seed, 0u, p.pixel, p.sample);
         const f3 wo = -p.d;
         const f3 wi = mat_sample<kExt>(material, u01(rb.x), u01(rb.y), u01(rb.z), wo, normal);
@@ -1766,20 +1848,21 @@ HD void finish_bounce(Path& p) {  // :268-271
         p.rad = mk(0.0f);
 }
 template <bool kExt>
-HD int shade_a(const DevScene& S, Path& p, int hit_tri, double hit_t, f3& so, f3& wi, float& tmax, LightSample& ls) {
+HD int shade_a(const DevScene& S, const ShadeSrc& src, Path& p, int hit_tri, double hit_t, f3& so, f3& wi, float& tmax, LightSample& ls) {
     if (hit_tri < 0) {
         finish_bounce(p);
         return kShadeMiss;
     }
     const f3 coords = p.o + p.d * (float)hit_t;  // Ray::operator(), Ray.hpp:27
     {
-        const DevMaterial& material = hit_material<kExt>(S, hit_tri, p.diffused);
+        const float light_pdf_of_hit = src.T[4 * hit_tri].w;  // (fetched with the material index, not after the material)
+        const DevMaterial& material = hit_material<kExt>(S, src, hit_tri, p.diffused);
         if (material.flags & kMatEmitting) {  // :164-184
             const f3 radiance = mk(material.emission[0], material.emission[1], material.emission[2]);
             if (p.depth == 0 || p.specular) {
                 p.rad = p.rad + p.thr * radiance;
             } else {
-                const float weight = powerHeuristic(p.pdf, S.tris[4 * hit_tri].w);
+                const float weight = powerHeuristic(p.pdf, light_pdf_of_hit);
                 p.rad = p.rad + p.thr * radiance * weight;
             }
         }
@@ -1787,42 +1870,10 @@ HD int shade_a(const DevScene& S, Path& p, int hit_tri, double hit_t, f3& so, f3
     if (p.specular) return kShadeNoShadowRay;
     // Scene::sampleLight (:99-120)
     const u4 ra = philox4x32_10((uint32_t)p.depth, 0u, S.seed, 0u, p.pixel, p.sample);
-    float lightSamplePdf = 0.0f, lightPdf = 0.0f;
-    f3 lx = mk(0.f), ln = mk(0.f);
-    uint32_t light = 0;
-    {
-        const float pick = u01(ra.x) * S.sum_light_area;
-        float emit_area_sum = 0;
-        for (uint32_t k = 0; k < S.num_lights; ++k) {
-            const DevLight& L = S.lights[k];
-            emit_area_sum += L.area;
-            if (pick <= emit_area_sum) {
-                // BVHAccel::Sample / getSample (BVH.hpp:147-184)
-                float q = sqrt_rn(u01(ra.y)) * L.root_area;
-                uint32_t node = L.root_node;
-                int tri;
-                while ((tri = __float_as_int(S.nodes[2 * node + 1].w)) < 0) {
-                    const uint32_t left = node + 1;
-                    const float la = S.node_area[left];
-                    if (q < la) node = left;
-                    else {
-                        q -= la;
-                        node = (uint32_t)__float_as_int(S.nodes[2 * left].w);
-                    }
-                }
-                // Triangle::Sample (Triangle.hpp:75-82)
-                const float sx = sqrt_rn(u01(ra.z)), sy = u01(ra.w);
-                const float4 a0 = S.tris[4 * tri], a3 = S.tris[4 * tri + 3];
-                const float4 b1 = S.tri_v12[2 * tri], b2 = S.tri_v12[2 * tri + 1];
-                lx = xyz(a0) * (1.0f - sx) + xyz(b1) * (sx * (1.0f - sy)) + xyz(b2) * (sx * sy);
-                ln = xyz(a3);
-                lightPdf = a0.w;
-                lightSamplePdf = L.inv_root_area;
-                light = k;
-                break;
-            }
-        }
-    }
+    const LightPoint lp = sample_light(S, src, ra);
+    const float lightSamplePdf = lp.lightSamplePdf, lightPdf = lp.lightPdf;
+    const f3 lx = lp.x, ln = lp.n;
+    const uint32_t light = lp.light;
     if (!(lightSamplePdf > 0.0f)) return kShadeNoShadowRay;
     const f3 px = lx - coords;
     wi = normalize(px);
@@ -1837,14 +1888,13 @@ HD int shade_a(const DevScene& S, Path& p, int hit_tri, double hit_t, f3& so, f3
 }
 // lit: a shadow ray towards the light sample `ls` along `wi` was traced and found nothing
 template <bool kExt>
-HD void shade_b(const DevScene& S, Path& p, int hit_tri, double hit_t, bool lit, f3 wi_light, const LightSample& ls) {
+HD void shade_b(const DevScene& S, const ShadeSrc& src, Path& p, int hit_tri, double hit_t, bool lit, f3 wi_light, const LightSample& ls) {
     const f3 coords = p.o + p.d * (float)hit_t;
-    const f3 normal = hit_normal<kExt>(S, hit_tri, coords);
-    const DevMaterial& material = hit_material<kExt>(S, hit_tri, p.diffused);
+    const f3 normal = hit_normal<kExt>(S, src, hit_tri, coords);
+    const DevMaterial& material = hit_material<kExt>(S, src, hit_tri, p.diffused);
     const f3 wo = -p.d;
     if (lit) {  // :208-227
-        const DevLight& L = S.lights[ls.light];
-        const f3 lemit = mk(L.emission[0], L.emission[1], L.emission[2]);
+        const f3 lemit = light_emission(S, src, ls.light);
         f3 bsdf;
         float bsdfPdf;
         mat_eval<kExt>(material, wi_light, wo, normal, bsdf, bsdfPdf);
