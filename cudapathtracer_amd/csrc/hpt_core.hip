@@ -715,7 +715,7 @@ __device__ __forceinline__ void schedule_wave(const DevScene& S, const float4* l
             // rounds of triangle tests: every lane that has a triangle to test takes part (also lanes
             // that could still step: the round costs the same), until too few lanes are blocked
             do {
-                if (st == kLaneWalk && Trav::may_test(W)) Trav::test_one(S, lds, tq, W COUNT_PASS);
+                if (st == kLaneWalk && Trav::may_test(W)) Trav::template test_one<kExt>(S, lds, tq, W COUNT_PASS);
             } while ((uint32_t)__popcll(__ballot(st == kLaneWalk && Trav::wants_test(W))) >= HPT_SM_T_TRI);
         } else if (what == 3) {
             if (st == kLaneShadeA) {

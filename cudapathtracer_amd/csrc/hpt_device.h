@@ -529,8 +529,11 @@ HD bool tri_hit(const float4* __restrict__ T, int tri, f3 o, f3 d, double& t_out
 // (flag word, normal, e1/e2, v0: each waits for the one before), and a wave runs the whole test anyway while any
 // of its lanes goes on.  Every comparison is the reference's, in its order and with its NaN behaviour (a NaN passes
 // `u < 0 || u > 1` there too); a stage that has failed only keeps later stages from mattering.
+// kSpheres = false: the caller knows that the scene holds no sphere (the kernels built without kExt: a sphere makes a
+// scene take the others); without the branch on the record's flag all four pieces are wanted at once.
+template <bool kSpheres = true>
 HD bool tri_hit_record(const float4 r0, const float4 r1, const float4 r2, const float4 r3, f3 o, f3 d, double& t_out) {
-    if (__float_as_uint(r3.w) & kSphereBit) {  // Sphere::getIntersection on (center, radius^2)
+    if (kSpheres && (__float_as_uint(r3.w) & kSphereBit)) {  // Sphere::getIntersection on (center, radius^2)
         const f3 L = o - xyz(r0);
         const float a = dot(d, d);
         const float b = 2 * dot(d, L);
@@ -1171,7 +1174,7 @@ HD void walk_step_record(const DevScene& S, const float4 q0, const float4 q1, co
 }
 
 // test the triangle queued last (requires W.cnt > 0)
-template <int kScene>
+template <int kScene, bool kSpheres = true>
 HD void walk_test_one(const DevScene& S, const float4* __restrict__ T, TriQueue tq, Walk& W COUNT_ARG) {
     constexpr bool kCull = (kScene == kScenePairCull);
     --W.cnt;
@@ -1179,7 +1182,7 @@ HD void walk_test_one(const DevScene& S, const float4* __restrict__ T, TriQueue 
     double t;
     COUNT_TRI(1);
     const float4 r0 = T[4 * tri], r1 = T[4 * tri + 1], r2 = T[4 * tri + 2], r3 = T[4 * tri + 3];  // one fetch of the whole record
-    if (tri_hit_record(r0, r1, r2, r3, W.o, W.d, t)) {
+    if (tri_hit_record<kSpheres>(r0, r1, r2, r3, W.o, W.d, t)) {
         if (W.shadow) {
             if (t < (double)W.tmax - (double)kEpsilon4) {  // BVH.hpp:121-127: occluded, the query ends
                 W.best = tri;
@@ -1247,8 +1250,9 @@ struct PairTraversal {
         if constexpr (coop_variant(kScene)) walk_step_staged<kScene>(S, tq, W COUNT_PASS);
         else walk_step<kScene>(S, records(S, lds), tq, W COUNT_PASS);
     }
+    template <bool kSpheres = true>
     HD static void test_one(const DevScene& S, const float4* lds, TriQueue tq, State& W COUNT_ARG) {
-        walk_test_one<kScene>(S, triangles(S, lds), tq, W COUNT_PASS);
+        walk_test_one<kScene, kSpheres>(S, triangles(S, lds), tq, W COUNT_PASS);
     }
     HD static void settle(const DevScene&, const float4*, State& COUNT_ARG) {}
 };
@@ -1346,6 +1350,7 @@ struct MarkTraversal {
             }
         }
     }
+    template <bool kSpheres = true>
     HD static void test_one(const DevScene& S, const float4* lds, TriQueue, State& W COUNT_ARG) {
         const float4* T = triangles(S, lds);
         const int tri = kMask32 ? __ffs((int)W.pending) - 1 : __ffsll((long long)W.pending) - 1;
@@ -1840,6 +1845,10 @@ HD bool shade_bounce(const DevScene& S, const float4* __restrict__ lds, TriQueue
 struct LightSample {
     float lightPdf, lightSamplePdf, cos_theta_prime, r2;
     uint32_t light;
+    // the hit's shading normal and its material's index (table offset included), read once in shade_a: shade_b starts
+    // without a fetch of its own
+    f3 normal;
+    uint32_t material;
 };
 enum { kShadeMiss = 0, kShadeShadowRay = 1, kShadeNoShadowRay = 2 };
 HD void finish_bounce(Path& p) {  // :268-271
@@ -1855,8 +1864,15 @@ HD int shade_a(const DevScene& S, const ShadeSrc& src, Path& p, int hit_tri, dou
     }
     const f3 coords = p.o + p.d * (float)hit_t;  // Ray::operator(), Ray.hpp:27
     {
-        const float light_pdf_of_hit = src.T[4 * hit_tri].w;  // (fetched with the material index, not after the material)
-        const DevMaterial& material = hit_material<kExt>(S, src, hit_tri, p.diffused);
+        // one fetch: material index, normal and the triangle's MIS light pdf
+        const float light_pdf_of_hit = src.T[4 * hit_tri].w;
+        uint32_t m = (uint32_t)__float_as_int(src.T[4 * hit_tri + 1].w);
+        ls.normal = hit_normal<kExt>(S, src, hit_tri, coords);
+        if constexpr (kExt) {
+            if ((S.integrator & kIntegratorRegularize) && p.diffused) m += S.num_mats;
+        }
+        ls.material = m;
+        const DevMaterial& material = src.M[m];
         if (material.flags & kMatEmitting) {  // :164-184
             const f3 radiance = mk(material.emission[0], material.emission[1], material.emission[2]);
             if (p.depth == 0 || p.specular) {
@@ -1890,8 +1906,8 @@ HD int shade_a(const DevScene& S, const ShadeSrc& src, Path& p, int hit_tri, dou
 template <bool kExt>
 HD void shade_b(const DevScene& S, const ShadeSrc& src, Path& p, int hit_tri, double hit_t, bool lit, f3 wi_light, const LightSample& ls) {
     const f3 coords = p.o + p.d * (float)hit_t;
-    const f3 normal = hit_normal<kExt>(S, src, hit_tri, coords);
-    const DevMaterial& material = hit_material<kExt>(S, src, hit_tri, p.diffused);
+    const f3 normal = ls.normal;
+    const DevMaterial& material = src.M[ls.material];
     const f3 wo = -p.d;
     if (lit) {  // :208-227
         const f3 lemit = light_emission(S, src, ls.light);
