@@ -668,6 +668,7 @@ __device__ __forceinline__ void schedule_wave(const DevScene& S, const float4* l
     Path p;
     int hit_tri = -1;
     double hit_t = 0.0;
+    constexpr bool kHave = Trav::kKeepsHitData && !kExt;  // the walk keeps the hit's normal and material index: they go into `ls` when it ends
     LightSample ls{};
     bool lit = false;  // kLaneShadeB: a shadow ray was traced (its answer is in W)
     for (;;) {
@@ -721,7 +722,7 @@ __device__ __forceinline__ void schedule_wave(const DevScene& S, const float4* l
             if (st == kLaneShadeA) {
                 f3 so, wi;
                 float tmax;
-                const int rc = shade_a<kExt>(S, src, p, hit_tri, hit_t, so, wi, tmax, ls);
+                const int rc = shade_a<kExt, kHave>(S, src, p, hit_tri, hit_t, so, wi, tmax, ls);
                 if (rc == kShadeMiss) {
                     pol.finish(p);
                     st = kLaneIdle;
@@ -759,6 +760,10 @@ __device__ __forceinline__ void schedule_wave(const DevScene& S, const float4* l
                 } else {
                     hit_tri = W.best;
                     hit_t = W.best_t;
+                    if constexpr (kHave) {
+                        ls.normal = W.best_n;
+                        ls.material = W.best_m;
+                    }
                     st = kLaneShadeA;
                 }
             }

@@ -1039,6 +1039,10 @@ struct Walk {
     float tmax;         // any-hit: Ray::shadowDistance (a float's value, Scene.hpp:203)
     float cull_t;       // kScenePairCull only
     bool finite, shadow;
+    // closest-hit walks of scenes without spheres: normal and material index of `best`, kept from its record when the
+    // test accepted it, so that the shading need not fetch the record again
+    f3 best_n;
+    uint32_t best_m;
 };
 template <int kScene>
 HD bool walk_can_step(const Walk& W) { return W.cur >= 0 && W.cnt + 2u <= tri_queue_entries(kScene); }
@@ -1194,6 +1198,10 @@ HD void walk_test_one(const DevScene& S, const float4* __restrict__ T, TriQueue 
         } else if (t < W.best_t || (t == W.best_t && tri < W.best)) {
             W.best = tri;
             W.best_t = t;
+            if constexpr (!kSpheres) {
+                W.best_n = xyz(r3);
+                W.best_m = __float_as_uint(r1.w);
+            }
             if constexpr (kCull) W.cull_t = (float)t * 1.000001f + S.cull_slack;
         }
     }
@@ -1228,6 +1236,7 @@ struct Traversal;
 template <int kScene>
 struct PairTraversal {
     using State = Walk;
+    static constexpr bool kKeepsHitData = true;  // (for test_one<false>) State::best_n / best_m describe State::best
     HD static void init(State& W) {
         W.cur = -1;
         W.cnt = 0u;
@@ -1263,6 +1272,7 @@ template <> struct Traversal<kScenePairCull> : PairTraversal<kScenePairCull> {};
 template <int kScene>
 struct MarkTraversal {
     static constexpr bool kMask32 = (kScene == kSceneTiny32);
+    static constexpr bool kKeepsHitData = false;
     using State = MarkWalk<kMask32>;
     using mask_t = typename State::mask_t;
     HD static void init(State& W) {
@@ -1856,7 +1866,9 @@ HD void finish_bounce(Path& p) {  // :268-271
     if (isnan(p.rad.x) || isnan(p.rad.y) || isnan(p.rad.z) || isinf(p.rad.x) || isinf(p.rad.y) || isinf(p.rad.z))
         p.rad = mk(0.0f);
 }
-template <bool kExt>
+// kHave: the walk kept the hit's normal and material index and the caller has put them into ls.normal / ls.material;
+// else they are fetched here
+template <bool kExt, bool kHave = false>
 HD int shade_a(const DevScene& S, const ShadeSrc& src, Path& p, int hit_tri, double hit_t, f3& so, f3& wi, float& tmax, LightSample& ls) {
     if (hit_tri < 0) {
         finish_bounce(p);
@@ -1864,10 +1876,14 @@ HD int shade_a(const DevScene& S, const ShadeSrc& src, Path& p, int hit_tri, dou
     }
     const f3 coords = p.o + p.d * (float)hit_t;  // Ray::operator(), Ray.hpp:27
     {
-        // one fetch: material index, normal and the triangle's MIS light pdf
-        const float light_pdf_of_hit = src.T[4 * hit_tri].w;
-        uint32_t m = (uint32_t)__float_as_int(src.T[4 * hit_tri + 1].w);
-        ls.normal = hit_normal<kExt>(S, src, hit_tri, coords);
+        uint32_t m;
+        if constexpr (kHave && !kExt) {
+            m = ls.material;
+        } else {
+            // one fetch: material index and normal
+            m = (uint32_t)__float_as_int(src.T[4 * hit_tri + 1].w);
+            ls.normal = hit_normal<kExt>(S, src, hit_tri, coords);
+        }
         if constexpr (kExt) {
             if ((S.integrator & kIntegratorRegularize) && p.diffused) m += S.num_mats;
         }
@@ -1878,6 +1894,7 @@ HD int shade_a(const DevScene& S, const ShadeSrc& src, Path& p, int hit_tri, dou
             if (p.depth == 0 || p.specular) {
                 p.rad = p.rad + p.thr * radiance;
             } else {
+                const float light_pdf_of_hit = src.T[4 * hit_tri].w;  // (few paths come here: the light was hit)
                 const float weight = powerHeuristic(p.pdf, light_pdf_of_hit);
                 p.rad = p.rad + p.thr * radiance * weight;
             }
