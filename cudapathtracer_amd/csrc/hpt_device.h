@@ -677,7 +677,7 @@ __host__ __device__ constexpr uint32_t tri_queue_entries(int scene) {
 }
 struct TriQueue {
     uint32_t* q;
-    uint32_t stride;
+    uint32_t stride;  // entries are addressed as q[__umul24(k, stride)]: both factors are small, and the 24-bit multiply is a full-rate instruction (the 32-bit one is quarter rate)
     uint32_t* stk;  // traversal stack of the pair variants: entry k of a lane at stk[k * stride]
     uint32_t stage; // cooperative record fetch (coop_fetch below): LDS byte address of this wave's staging area
 };
@@ -742,7 +742,7 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
         if (finite) {
             // walk the copy of this ray's octant; `at` is the node's LDS address, links are addresses too
             const uint32_t oct = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
-            uint32_t at = nbase + oct * copy_bytes;
+            uint32_t at = nbase + __umul24(oct, copy_bytes);  // (the 32-bit integer multiply is a quarter-rate instruction)
             const uint32_t stop = at + table[oct] * 32u;
             while (at < stop) {
                 PROF_ITER(kShadow ? kProfBoxS : kProfBoxC);
@@ -899,11 +899,11 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
                 }
                 const int rl = __float_as_int(q0.w), rr = __float_as_int(q1.w);
                 if (hl && rl < 0) {
-                    tq.q[cnt * tq.stride] = (uint32_t)~rl;
+                    tq.q[__umul24(cnt, tq.stride)] = (uint32_t)~rl;
                     ++cnt;
                 }
                 if (hr && rr < 0) {
-                    tq.q[cnt * tq.stride] = (uint32_t)~rr;
+                    tq.q[__umul24(cnt, tq.stride)] = (uint32_t)~rr;
                     ++cnt;
                 }
                 const bool gl = hl && rl >= 0, gr = hr && rr >= 0;
@@ -912,10 +912,10 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
                         const bool right_first = tnr < tnl;
                         const float tfar_child = right_first ? tnl : tnr;
                         const uint32_t qd = (uint32_t)fminf(fmaxf(tfar_child, 0.f) * S.cull_qscale, 1023.f);
-                        tq.stk[sp * tq.stride] = (uint32_t)(right_first ? rl : rr) | (qd << 22);
+                        tq.stk[__umul24(sp, tq.stride)] = (uint32_t)(right_first ? rl : rr) | (qd << 22);
                         cur = right_first ? rr : rl;
                     } else {
-                        tq.stk[sp * tq.stride] = (uint32_t)rr;
+                        tq.stk[__umul24(sp, tq.stride)] = (uint32_t)rr;
                         cur = rl;
                     }
                     ++sp;
@@ -927,7 +927,7 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
                     cur = -1;
                     while (sp) {
                         --sp;
-                        uint32_t e = tq.stk[sp * tq.stride];
+                        uint32_t e = tq.stk[__umul24(sp, tq.stride)];
                         if constexpr (kCull) {
                             if ((float)(e >> 22) * S.cull_qinv > cull_t) continue;
                             e &= 0x3FFFFFu;
@@ -939,7 +939,7 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
             }
             if (cnt == 0) break;
             for (uint32_t k = 0; k < cnt; ++k) {
-                const int tri = (int)tq.q[k * tq.stride];
+                const int tri = (int)tq.q[__umul24(k, tq.stride)];
                 double t;
                 COUNT_TRI(1);
                 const float4 r0 = T[4 * tri], r1 = T[4 * tri + 1], r2 = T[4 * tri + 2], r3 = T[4 * tri + 3];  // one fetch of the whole record
@@ -986,14 +986,14 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
                 const bool hit = finite ? box_hit_finite(lo, hi, o, inv) : box_hit(lo, hi, o, inv, nx, ny, nz);
                 const int tri = __float_as_int(hi.w);
                 if (hit && tri >= 0) {
-                    tq.q[cnt * tq.stride] = (uint32_t)tri;
+                    tq.q[__umul24(cnt, tq.stride)] = (uint32_t)tri;
                     ++cnt;
                 }
                 node = hit ? node + 1 : __float_as_int(lo.w);
             }
             if (cnt == 0) break;
             for (uint32_t k = 0; k < cnt; ++k) {
-                const int tri = (int)tq.q[k * tq.stride];
+                const int tri = (int)tq.q[__umul24(k, tq.stride)];
                 double t;
                 COUNT_TRI(1);
                 const float4 r0 = T[4 * tri], r1 = T[4 * tri + 1], r2 = T[4 * tri + 2], r3 = T[4 * tri + 3];  // one fetch of the whole record
@@ -1138,11 +1138,11 @@ HD void walk_step_record(const DevScene& S, const float4 q0, const float4 q1, co
     }
     const int rl = __float_as_int(q0.w), rr = __float_as_int(q1.w);
     if (hl && rl < 0) {
-        tq.q[W.cnt * tq.stride] = (uint32_t)~rl;
+        tq.q[__umul24(W.cnt, tq.stride)] = (uint32_t)~rl;
         ++W.cnt;
     }
     if (hr && rr < 0) {
-        tq.q[W.cnt * tq.stride] = (uint32_t)~rr;
+        tq.q[__umul24(W.cnt, tq.stride)] = (uint32_t)~rr;
         ++W.cnt;
     }
     const bool gl = hl && rl >= 0, gr = hr && rr >= 0;
@@ -1151,10 +1151,10 @@ HD void walk_step_record(const DevScene& S, const float4 q0, const float4 q1, co
             const bool right_first = tnr < tnl;
             const float tfar_child = right_first ? tnl : tnr;
             const uint32_t qd = (uint32_t)fminf(fmaxf(tfar_child, 0.f) * S.cull_qscale, 1023.f);
-            tq.stk[W.sp * tq.stride] = (uint32_t)(right_first ? rl : rr) | (qd << 22);
+            tq.stk[__umul24(W.sp, tq.stride)] = (uint32_t)(right_first ? rl : rr) | (qd << 22);
             W.cur = right_first ? rr : rl;
         } else {
-            tq.stk[W.sp * tq.stride] = (uint32_t)rr;
+            tq.stk[__umul24(W.sp, tq.stride)] = (uint32_t)rr;
             W.cur = rl;
         }
         ++W.sp;
@@ -1166,7 +1166,7 @@ HD void walk_step_record(const DevScene& S, const float4 q0, const float4 q1, co
         W.cur = -1;
         while (W.sp) {
             --W.sp;
-            uint32_t e = tq.stk[W.sp * tq.stride];
+            uint32_t e = tq.stk[__umul24(W.sp, tq.stride)];
             if constexpr (kCull) {
                 if ((float)(e >> 22) * S.cull_qinv > W.cull_t) continue;
                 e &= 0x3FFFFFu;
@@ -1182,7 +1182,7 @@ template <int kScene, bool kSpheres = true>
 HD void walk_test_one(const DevScene& S, const float4* __restrict__ T, TriQueue tq, Walk& W COUNT_ARG) {
     constexpr bool kCull = (kScene == kScenePairCull);
     --W.cnt;
-    const int tri = (int)tq.q[W.cnt * tq.stride];
+    const int tri = (int)tq.q[__umul24(W.cnt, tq.stride)];
     double t;
     COUNT_TRI(1);
     const float4 r0 = T[4 * tri], r1 = T[4 * tri + 1], r2 = T[4 * tri + 2], r3 = T[4 * tri + 3];  // one fetch of the whole record
@@ -1589,6 +1589,10 @@ struct ShadeSrc {
     const float4* T;
     const DevMaterial* M;
     const float4* L;  // DevScene::fast_light's copy in LDS, or null
+    // M[m] with a 24-bit multiply for the offset (the 32-bit one is a quarter-rate instruction)
+    HD const DevMaterial& material(uint32_t m) const {
+        return *reinterpret_cast<const DevMaterial*>(reinterpret_cast<const char*>(M) + __umul24(m, (uint32_t)sizeof(DevMaterial)));
+    }
 };
 template <int kScene, bool kExt>
 HD ShadeSrc shade_source(const DevScene& S, const float4* lds) {
@@ -1680,7 +1684,7 @@ HD const DevMaterial& hit_material(const DevScene& S, const ShadeSrc& src, int h
     if constexpr (kExt) {
         if ((S.integrator & kIntegratorRegularize) && diffused) m += S.num_mats;
     }
-    return src.M[m];
+    return src.material(m);
 }
 template <bool kExt>
 HD f3 hit_normal(const DevScene& S, const ShadeSrc& src, int hit_tri, f3 coords) {
@@ -1888,7 +1892,7 @@ HD int shade_a(const DevScene& S, const ShadeSrc& src, Path& p, int hit_tri, dou
             if ((S.integrator & kIntegratorRegularize) && p.diffused) m += S.num_mats;
         }
         ls.material = m;
-        const DevMaterial& material = src.M[m];
+        const DevMaterial& material = src.material(m);
         if (material.flags & kMatEmitting) {  // :164-184
             const f3 radiance = mk(material.emission[0], material.emission[1], material.emission[2]);
             if (p.depth == 0 || p.specular) {
@@ -1924,7 +1928,7 @@ template <bool kExt>
 HD void shade_b(const DevScene& S, const ShadeSrc& src, Path& p, int hit_tri, double hit_t, bool lit, f3 wi_light, const LightSample& ls) {
     const f3 coords = p.o + p.d * (float)hit_t;
     const f3 normal = ls.normal;
-    const DevMaterial& material = src.M[ls.material];
+    const DevMaterial& material = src.material(ls.material);
     const f3 wo = -p.d;
     if (lit) {  // :208-227
         const f3 lemit = light_emission(S, src, ls.light);

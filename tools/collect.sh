@@ -11,7 +11,7 @@ cd $GRAFT_REPO_ROOT
 B="timeout -k 10 300 python bench.py"
 # the headline line (with the CPU baseline leg), and the other configurations as side measurements
 $B > $OUT/bench_cornell_mode1.json 2> $OUT/bench.err || exit 1
-$B --mode 2 --steps 4 --warmup 1 > $OUT/bench_cornell_mode2.json 2>> $OUT/bench.err || exit 1
+$B --mode 2 --steps 4 --warmup 1 --no-cpu-baseline > $OUT/bench_cornell_mode2.json 2>> $OUT/bench.err || exit 1
 # (steps of many samples: the single kernel needs them to amortise the end of a launch -- 16 spp of 1024^2 are 4 work
 #  units per resident wave -- and the streamed mode to fill its batches of up to 2^28 paths)
 for m in 1 2; do
@@ -20,8 +20,8 @@ for m in 1 2; do
   $B --scene heightfield:708 --width 2048 --height 2048 --mode $m --steps 3 --warmup 1 --spp-per-step $SH > $OUT/bench_heightfield708_mode$m.json 2>> $OUT/bench.err || exit 1
   $B --no-cpu-baseline --traversal culled --scene bunny --mode $m --steps 3 --warmup 1 --spp-per-step $SB > $OUT/bench_bunny_culled_mode$m.json 2>> $OUT/bench.err || exit 1
   $B --no-cpu-baseline --traversal culled --scene heightfield:708 --width 2048 --height 2048 --mode $m --steps 2 --warmup 1 --spp-per-step $SH > $OUT/bench_heightfield708_culled_mode$m.json 2>> $OUT/bench.err || exit 1
-  $B --no-cpu-baseline --bvh-build sah --scene bunny --mode $m --steps 3 --warmup 1 --spp-per-step $SB > $OUT/bench_bunny_sah_mode$m.json 2>> $OUT/bench.err || exit 1
-  $B --no-cpu-baseline --bvh-build sah --scene heightfield:708 --width 2048 --height 2048 --mode $m --steps 2 --warmup 1 --spp-per-step $SH > $OUT/bench_heightfield708_sah_mode$m.json 2>> $OUT/bench.err || exit 1
+  $B --no-cpu-baseline --bvh-build host --scene bunny --mode $m --steps 3 --warmup 1 --spp-per-step $SB > $OUT/bench_bunny_reftree_mode$m.json 2>> $OUT/bench.err || exit 1
+  $B --no-cpu-baseline --bvh-build host --scene heightfield:708 --width 2048 --height 2048 --mode $m --steps 2 --warmup 1 --spp-per-step $SH > $OUT/bench_heightfield708_reftree_mode$m.json 2>> $OUT/bench.err || exit 1
 done
 $B --scene glass --steps 4 --warmup 1 > $OUT/bench_glass_mode1.json 2>> $OUT/bench.err || exit 1
 HPT_BENCH_FORCE_DIST=1 $B --no-cpu-baseline --steps 4 --warmup 1 > $OUT/bench_cornell_mode1_rccl_1rank.json 2>> $OUT/bench.err || exit 1
@@ -42,7 +42,8 @@ export HPT_MODELS_DIR=$GRAFT_REPO_ROOT/models
 ( HPT_WIDTH=1024 HPT_HEIGHT=1024 timeout -k 10 300 $GRAFT_REPO_ROOT/build/gpu_path_tracer 4096 20 256 1 ) > $OUT/cli_config2.txt 2>&1 || exit 1
 ( HPT_SCENE=bunny HPT_WIDTH=1024 HPT_HEIGHT=1024 timeout -k 10 300 $GRAFT_REPO_ROOT/build/gpu_path_tracer 1024 20 256 2 ) > $OUT/cli_config3.txt 2>&1 || exit 1
 ( HPT_SCENE=heightfield:708 HPT_WIDTH=2048 HPT_HEIGHT=2048 timeout -k 10 600 $GRAFT_REPO_ROOT/build/gpu_path_tracer 128 20 256 2 ) > $OUT/cli_config5_128spp.txt 2>&1 || exit 1
-( HPT_BVH=sah HPT_SCENE=bunny HPT_WIDTH=1024 HPT_HEIGHT=1024 timeout -k 10 300 $GRAFT_REPO_ROOT/build/gpu_path_tracer 1024 20 256 2 ) > $OUT/cli_config3_sah.txt 2>&1 || exit 1
-( HPT_BVH=sah HPT_SCENE=heightfield:708 HPT_WIDTH=2048 HPT_HEIGHT=2048 timeout -k 10 600 $GRAFT_REPO_ROOT/build/gpu_path_tracer 128 20 256 2 ) > $OUT/cli_config5_128spp_sah.txt 2>&1 || exit 1
+( HPT_SCENE=heightfield:708 HPT_WIDTH=2048 HPT_HEIGHT=2048 timeout -k 10 600 $GRAFT_REPO_ROOT/build/gpu_path_tracer 1024 20 256 2 ) > $OUT/cli_config5_1024spp.txt 2>&1 || exit 1
+( HPT_BVH=reference HPT_SCENE=bunny HPT_WIDTH=1024 HPT_HEIGHT=1024 timeout -k 10 300 $GRAFT_REPO_ROOT/build/gpu_path_tracer 1024 20 256 2 ) > $OUT/cli_config3_reftree.txt 2>&1 || exit 1
+( HPT_GPUS=1 HPT_DEVICES=0,0 HPT_WIDTH=1024 HPT_HEIGHT=1024 timeout -k 10 300 $GRAFT_REPO_ROOT/build/gpu_path_tracer 4096 20 256 1 ) > $OUT/cli_config4_two_contexts_one_gpu.txt 2>&1 || exit 1
 rm -rf $OUT/cli
 echo collected

@@ -5,7 +5,7 @@
 
 Every case draws a scene (the Cornell shell or a bare light, plus random triangle soups, boxes of the reference's
 Cornell box, the bunny and spheres, with random Lambertian / microfacet / glass materials and sometimes a second
-emitter), an image size, depth, sample range, seed, render mode, workgroup size, integrator options and BVH builder (reference / device / SAH),
+emitter), an image size, depth, sample range, seed, render mode, workgroup size, integrator options and BVH builder (reference / device / SAH / the default),
 and compares -- bit for bit -- the fixed-point accumulators and the ray counters of hpt_render with the oracle's, the
 closest hits of a random ray batch, the occlusion answers of a shadow batch and the radiance of hpt_cast_rays.
 Prints one line per case and stops at the first difference with the case's seed (exit status 1)."""
@@ -87,6 +87,10 @@ def build_case(rs, orc, big=False):
             e = tuple(float(v) for v in rs.rand(3) * 20 + 1)
             items.append(("tris", soup(rs, int(rs.randint(1, 4)), 80.0), dict(type=0, emission=e)))
             what.append("emitter")
+    if rs.rand() < 0.1:   # many objects = many materials: more than the kernels keep in LDS
+        for _ in range(14):
+            items.append(("tris", soup(rs, int(rs.randint(1, 3)), 60.0), random_material(rs)))
+        what.append("14 small")
     order = rs.permutation(len(items))
     sc = hp.Scene(w, h, camPos=scenes.CORNELL_CAM, fov=40.0, maxDepth=depth)
     osc = orc.scene(w, h, scenes.CORNELL_CAM, 40.0)
@@ -98,8 +102,20 @@ def build_case(rs, orc, big=False):
         else:
             sc.AddSphere(it[1], it[2], hp.Material(**it[3]))
             osc.add_sphere(it[1], it[2], Material.make(**it[3]))
-    build = rs.choice(["host", "gpu", "sah"], p=[0.5, 0.25, 0.25])
-    sc.buildBVH(sah=True) if build == "sah" else sc.buildBVH(gpu=bool(build == "gpu"))
+    build = rs.choice(["host", "gpu", "sah", "auto"], p=[0.3, 0.2, 0.2, 0.3])   # auto = the library's default
+    # The same mesh twice = coincident triangles with different materials: every ray that hits them hits two triangles
+    # at bitwise the same distance.  The reference keeps the one its traversal meets first, and so does every host-built
+    # tree here (records in the reference's order); the device-built tree documents that it may name the other one
+    # (include/hpt.h, HPT_BVH_BUILD_GPU), which then shades with the other material.  Such scenes take a host build.
+    meshes_drawn = [x for x in what if x in ("shortbox", "tallbox", "bunny")]
+    if build == "gpu" and len(set(meshes_drawn)) != len(meshes_drawn):
+        build = "host"
+    if build == "auto":
+        sc.buildBVH()
+    elif build == "sah":
+        sc.buildBVH(sah=True)
+    else:
+        sc.buildBVH(gpu=bool(build == "gpu"))
     osc.build()
     # gpu_build: device-built records keep their own leaf order (ids may differ where several triangles are hit at one
     # distance); the SAH tree keeps the reference's record order, ids included
