@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU call that gathers the benchmark, profile and counter files kept under profiles/ for the current build:
-#   tools/collect.sh <tag> [bench]   (run on the GPU box from the repo root; results under gpurun_out/<tag>/;
+#   tools/collect.sh <tag> [bench|pmc]   (run on the GPU box from the repo root; results under gpurun_out/<tag>/;
 #                                     "bench": only the bench.py lines, e.g. after profiles/hbm_traffic.json changed)
 # Afterwards, here: tools/collect_summarise.sh <tag> turns them into profiles/<tag>_* and profiles/hbm_traffic.json.
 set -u
@@ -9,23 +9,25 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 B="timeout -k 10 300 python bench.py"
+if [ "${2:-}" != "pmc" ]; then   # ("pmc": only the counter / trace / CLI half, after a "bench" call)
 # the headline line (with the CPU baseline leg), and the other configurations as side measurements
 $B > $OUT/bench_cornell_mode1.json 2> $OUT/bench.err || exit 1
-$B --mode 2 --steps 4 --warmup 1 --no-cpu-baseline > $OUT/bench_cornell_mode2.json 2>> $OUT/bench.err || exit 1
+$B --mode 2 --steps 4 --warmup 1 --no-cpu-baseline --no-strong-leg > $OUT/bench_cornell_mode2.json 2>> $OUT/bench.err || exit 1
 # (steps of many samples: the single kernel needs them to amortise the end of a launch -- 16 spp of 1024^2 are 4 work
 #  units per resident wave -- and the streamed mode to fill its batches of up to 2^28 paths)
 for m in 1 2; do
   SB=256; SH=64
-  $B --scene bunny --mode $m --steps 4 --warmup 1 --spp-per-step $SB > $OUT/bench_bunny_mode$m.json 2>> $OUT/bench.err || exit 1
-  $B --scene heightfield:708 --width 2048 --height 2048 --mode $m --steps 3 --warmup 1 --spp-per-step $SH > $OUT/bench_heightfield708_mode$m.json 2>> $OUT/bench.err || exit 1
-  $B --no-cpu-baseline --traversal culled --scene bunny --mode $m --steps 3 --warmup 1 --spp-per-step $SB > $OUT/bench_bunny_culled_mode$m.json 2>> $OUT/bench.err || exit 1
-  $B --no-cpu-baseline --traversal culled --scene heightfield:708 --width 2048 --height 2048 --mode $m --steps 2 --warmup 1 --spp-per-step $SH > $OUT/bench_heightfield708_culled_mode$m.json 2>> $OUT/bench.err || exit 1
-  $B --no-cpu-baseline --bvh-build host --scene bunny --mode $m --steps 3 --warmup 1 --spp-per-step $SB > $OUT/bench_bunny_reftree_mode$m.json 2>> $OUT/bench.err || exit 1
-  $B --no-cpu-baseline --bvh-build host --scene heightfield:708 --width 2048 --height 2048 --mode $m --steps 2 --warmup 1 --spp-per-step $SH > $OUT/bench_heightfield708_reftree_mode$m.json 2>> $OUT/bench.err || exit 1
+  $B --no-strong-leg --scene bunny --mode $m --steps 4 --warmup 1 --spp-per-step $SB > $OUT/bench_bunny_mode$m.json 2>> $OUT/bench.err || exit 1
+  $B --no-strong-leg --scene heightfield:708 --width 2048 --height 2048 --mode $m --steps 3 --warmup 1 --spp-per-step $SH > $OUT/bench_heightfield708_mode$m.json 2>> $OUT/bench.err || exit 1
+  $B --no-strong-leg --no-cpu-baseline --traversal culled --scene bunny --mode $m --steps 3 --warmup 1 --spp-per-step $SB > $OUT/bench_bunny_culled_mode$m.json 2>> $OUT/bench.err || exit 1
+  $B --no-strong-leg --no-cpu-baseline --traversal culled --scene heightfield:708 --width 2048 --height 2048 --mode $m --steps 2 --warmup 1 --spp-per-step $SH > $OUT/bench_heightfield708_culled_mode$m.json 2>> $OUT/bench.err || exit 1
+  $B --no-strong-leg --no-cpu-baseline --bvh-build host --scene bunny --mode $m --steps 3 --warmup 1 --spp-per-step $SB > $OUT/bench_bunny_reftree_mode$m.json 2>> $OUT/bench.err || exit 1
+  $B --no-strong-leg --no-cpu-baseline --bvh-build host --scene heightfield:708 --width 2048 --height 2048 --mode $m --steps 2 --warmup 1 --spp-per-step $SH > $OUT/bench_heightfield708_reftree_mode$m.json 2>> $OUT/bench.err || exit 1
 done
-$B --scene glass --steps 4 --warmup 1 > $OUT/bench_glass_mode1.json 2>> $OUT/bench.err || exit 1
+$B --no-strong-leg --scene glass --steps 4 --warmup 1 > $OUT/bench_glass_mode1.json 2>> $OUT/bench.err || exit 1
 HPT_BENCH_FORCE_DIST=1 $B --no-cpu-baseline --steps 4 --warmup 1 > $OUT/bench_cornell_mode1_rccl_1rank.json 2>> $OUT/bench.err || exit 1
 [ "${2:-}" = "bench" ] && { echo collected; exit 0; }
+fi
 # counters and kernel traces: the headline kernel, and the streamed kernel on the two large scenes
 bash tools/pmc_scene.sh ${TAG}_cornell_m1 || exit 1
 bash tools/pmc_scene.sh ${TAG}_bunny_m2 --scene bunny --mode 2 --spp-per-step 256 || exit 1
