@@ -1207,7 +1207,7 @@ struct OctBox {
 // nodes per candidate.  Whatever comes out is a tree of unions over the same leaves, i.e. as exact as any other
 // (build_octant_copies).  Cornell box: 15.3 + 12.6 wave steps per bounce with the area rule, 14.5 + 11.3 after.
 void tune_octant_trees(const hpt_scene_desc* sc, std::vector<OctBox> (&pools)[8], std::vector<int> (&tops)[8]) {
-    constexpr int kRays = 8192, kWave = 64, kMaxSteps = 160, kMaxEvaluations = 6000;
+    constexpr int kRays = 8192, kWave = 64, kMaxSteps = 160, kMaxEvaluations = 3000;
     constexpr double kMeanWeight = 0.05, kMinGain = 1e-3;
     const uint32_t nt = sc->num_tris;
     // ---- rays ----
