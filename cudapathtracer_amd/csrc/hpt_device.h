@@ -744,6 +744,17 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
             const uint32_t oct = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
             uint32_t at = nbase + __umul24(oct, copy_bytes);  // (the 32-bit integer multiply is a quarter-rate instruction)
             const uint32_t stop = at + table[oct] * 32u;
+#ifdef HPT_BOX_TWICE  // diagnostic: the walk's cost = the time this adds
+            for (uint32_t at2 = at; at2 < stop;) {
+                const float4 nr = lds_read(at2), fr = lds_read(at2 + 16u);
+                const float tnear = fmaxf(fmaxf((nr.x - o.x) * inv.x, (nr.y - o.y) * inv.y), (nr.z - o.z) * inv.z);
+                const float tfar = fminf(fminf((fr.x - o.x) * inv.x, (fr.y - o.y) * inv.y), (fr.z - o.z) * inv.z);
+                const bool hit = tnear <= tfar;
+                pending |= hit ? (mask_t)__float_as_uint(fr.w) : (mask_t)0;
+                at2 = hit ? at2 + 32u : __float_as_uint(nr.w);
+                asm volatile("" ::: "memory");
+            }
+#endif
             while (at < stop) {
                 PROF_ITER(kShadow ? kProfBoxS : kProfBoxC);
                 COUNT_BOX(1);
