@@ -310,6 +310,58 @@ def test_octant_copies_reach_exactly_the_leaves_whose_boxes_are_hit(hp, scene_na
     assert total_new < 0.75 * total_ref        # and with fewer box tests
 
 
+def test_octant_trees_are_tuned_for_the_slowest_lane_of_a_wave(hp):
+    """The upload tunes the per-octant trees on sampled rays so that the LARGEST step count among the 64 rays of a
+    wave goes down (tune_octant_trees in csrc/hpt_core.hip; HPT_OCTANT_TUNE=0 keeps the area rule's trees).  Checked
+    here on rays drawn independently of the library's sample: origins on the Cornell box's surfaces, cosine-distributed
+    directions.  Both sets of copies mark the same triangles; the tuning is deterministic.  No GPU needed."""
+    import os
+    f32 = np.float32
+    sc = hp.Scene.CreateBuiltinScene(hp.Scene.CornellBox, 5, 16, 16)
+    flat = sc.flat_arrays()
+    nn = len(flat["nodes"])
+    tuned, table = sc.octant_copies(True)
+    again, table_again = sc.octant_copies(True)
+    assert np.array_equal(tuned.view(np.uint32), again.view(np.uint32)) and np.array_equal(table, table_again)
+    os.environ["HPT_OCTANT_TUNE"] = "0"
+    try:
+        plain, plain_table = sc.octant_copies(True)
+    finally:
+        del os.environ["HPT_OCTANT_TUNE"]
+    assert not np.array_equal(tuned.view(np.uint32), plain.view(np.uint32))
+    tris = flat["tris"]
+    rs = np.random.RandomState(21)
+    v0, e1, e2, nrm = (tris[:, a:a + 3].astype(float) for a in (0, 4, 8, 12))
+    area = 0.5 * np.linalg.norm(np.cross(e1, e2), axis=1)
+    n = 1280
+    t = rs.choice(len(tris), n, p=area / area.sum())
+    su, v = np.sqrt(rs.rand(n)), rs.rand(n)
+    p = v0[t] + e1[t] * (su * (1 - v))[:, None] + e2[t] * (su * v)[:, None]
+    r1, phi = rs.rand(n), 2 * np.pi * rs.rand(n)
+    N = nrm[t]
+    h = np.where(np.abs(N[:, [0]]) > 0.9, [[0.0, 1.0, 0.0]], [[1.0, 0.0, 0.0]])
+    T = np.cross(h, N)
+    T /= np.linalg.norm(T, axis=1, keepdims=True)
+    B = np.cross(N, T)
+    d = (T * (np.sqrt(r1) * np.cos(phi))[:, None] + B * (np.sqrt(r1) * np.sin(phi))[:, None] + N * np.sqrt(1 - r1)[:, None]).astype(f32)
+    o = p.astype(f32)
+    steps_tuned, steps_plain = [], []
+    for oi, di in zip(o, d):
+        if (di == 0).any():
+            continue
+        inv = (f32(1.0) / di).astype(f32)
+        k = int(di[0] < 0) | int(di[1] < 0) << 1 | int(di[2] < 0) << 2
+        got_t, st = _walk_octant_copy(tuned, table, k, nn, oi, inv)
+        got_p, sp = _walk_octant_copy(plain, plain_table, k, nn, oi, inv)
+        assert got_t == got_p
+        steps_tuned.append(st)
+        steps_plain.append(sp)
+    m = len(steps_tuned) // 64 * 64
+    wave_tuned = np.array(steps_tuned[:m]).reshape(-1, 64).max(axis=1).mean()
+    wave_plain = np.array(steps_plain[:m]).reshape(-1, 64).max(axis=1).mean()
+    assert wave_tuned < wave_plain, (wave_tuned, wave_plain)
+
+
 def test_scene_errors(hp, tmp_path):
     with pytest.raises(hp.HptError):
         hp.Scene.CreateBuiltinScene(hp.Scene.CornellBox, 5, models_dir=str(tmp_path))
