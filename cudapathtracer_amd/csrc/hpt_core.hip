@@ -671,32 +671,73 @@ __device__ __forceinline__ void schedule_wave(const DevScene& S, const float4* l
     constexpr bool kHave = Trav::kKeepsHitData && !kExt;  // the walk keeps the hit's normal and material index: they go into `ls` when it ends
     LightSample ls{};
     bool lit = false;  // kLaneShadeB: a shadow ray was traced (its answer is in W)
-    for (;;) {
-        const bool walking = st == kLaneWalk;
-        const bool can_step = walking && Trav::can_step(W);
-        const bool wants_test = walking && Trav::wants_test(W);
-        const uint32_t c_step = (uint32_t)__popcll(__ballot(can_step));
-        const uint32_t c_tri = (uint32_t)__popcll(__ballot(wants_test));
-        const uint32_t c_a = (uint32_t)__popcll(__ballot(st == kLaneShadeA));
-        const uint32_t c_b = (uint32_t)__popcll(__ballot(st == kLaneShadeB));
-        const unsigned long long m_idle = __ballot(st == kLaneIdle);
-        const uint32_t c_idle = m_idle ? pol.refillable(m_idle, __ballot(st != kLaneIdle)) : 0u;
-        // what to run: the first kind of round that reaches its threshold, else the most wanted
-        int what;  // 0 refill, 1 step, 2 triangles, 3 shade A, 4 shade B
-        if (c_idle >= HPT_SM_T_REFILL) what = 0;
-        else if (c_step >= HPT_SM_T_STEP) what = 1;
-        else if (c_tri >= HPT_SM_T_TRI) what = 2;
-        else if (c_b >= HPT_SM_T_SHADE) what = 4;
-        else if (c_a >= HPT_SM_T_SHADE) what = 3;
-        else {
-            uint32_t best = c_step;
-            what = 1;
-            if (c_tri > best) { best = c_tri; what = 2; }
-            if (c_b > best) { best = c_b; what = 4; }
-            if (c_a > best) { best = c_a; what = 3; }
-            if (c_idle > best) { best = c_idle; what = 0; }
-            if (best == 0u) break;  // every lane idle and nothing left to hand out
+    // walks that have just ended: the marking variants' back-face filter, then the lane goes to the shading
+    auto finish_walks = [&]() {
+        if (st == kLaneWalk) {
+            Trav::settle(S, lds, W COUNT_PASS);
+            if (Trav::done(W)) {
+                if (W.shadow) {
+                    st = kLaneShadeB;
+                } else {
+                    hit_tri = W.best;
+                    hit_t = W.best_t;
+                    if constexpr (kHave) {
+                        ls.normal = W.best_n;
+                        ls.material = W.best_m;
+                    }
+                    st = kLaneShadeA;
+                }
+            }
         }
+    };
+    for (;;) {
+        // The walking rounds form a loop of their own: most rounds are box steps and triangle tests, and inside this
+        // loop the path and shading state is untouched, so it stays where it is while the wave alternates between them.
+        int what;  // 0 refill, 1 step, 2 triangles, 3 shade A, 4 shade B, -1 nothing left
+        for (;;) {
+            const bool walking = st == kLaneWalk;
+            const bool can_step = walking && Trav::can_step(W);
+            const bool wants_test = walking && Trav::wants_test(W);
+            const uint32_t c_step = (uint32_t)__popcll(__ballot(can_step));
+            const uint32_t c_tri = (uint32_t)__popcll(__ballot(wants_test));
+            const uint32_t c_a = (uint32_t)__popcll(__ballot(st == kLaneShadeA));
+            const uint32_t c_b = (uint32_t)__popcll(__ballot(st == kLaneShadeB));
+            const unsigned long long m_idle = __ballot(st == kLaneIdle);
+            const uint32_t c_idle = m_idle ? pol.refillable(m_idle, __ballot(st != kLaneIdle)) : 0u;
+            // what to run: the first kind of round that reaches its threshold, else the most wanted
+            if (c_idle >= HPT_SM_T_REFILL) what = 0;
+            else if (c_step >= HPT_SM_T_STEP) what = 1;
+            else if (c_tri >= HPT_SM_T_TRI) what = 2;
+            else if (c_b >= HPT_SM_T_SHADE) what = 4;
+            else if (c_a >= HPT_SM_T_SHADE) what = 3;
+            else {
+                uint32_t best = c_step;
+                what = 1;
+                if (c_tri > best) { best = c_tri; what = 2; }
+                if (c_b > best) { best = c_b; what = 4; }
+                if (c_a > best) { best = c_a; what = 3; }
+                if (c_idle > best) { best = c_idle; what = 0; }
+                if (best == 0u) what = -1;  // every lane idle and nothing left to hand out
+            }
+            if (what == 1) {
+                // rounds of box steps while enough lanes take part
+                do {
+                    const bool stepping = st == kLaneWalk && Trav::can_step(W);
+                    Trav::fetch(S, lds, tq, W, stepping);  // every lane of the wave (the cooperative record fetch; nothing otherwise)
+                    if (stepping) Trav::step(S, lds, tq, W COUNT_PASS);
+                } while ((uint32_t)__popcll(__ballot(st == kLaneWalk && Trav::can_step(W))) >= HPT_SM_T_STEP);
+            } else if (what == 2) {
+                // rounds of triangle tests: every lane that has a triangle to test takes part (also lanes
+                // that could still step: the round costs the same), until too few lanes are blocked
+                do {
+                    if (st == kLaneWalk && Trav::may_test(W)) Trav::template test_one<kExt>(S, lds, tq, W COUNT_PASS);
+                } while ((uint32_t)__popcll(__ballot(st == kLaneWalk && Trav::wants_test(W))) >= HPT_SM_T_TRI);
+            } else {
+                break;
+            }
+            finish_walks();
+        }
+        if (what < 0) break;
         if (what == 0) {
             bool got = false;
             pol.refill(st == kLaneIdle, p, got);
@@ -705,19 +746,6 @@ __device__ __forceinline__ void schedule_wave(const DevScene& S, const float4* l
                 Trav::begin(S, lds, W, p.o, p.d, false, 0.f COUNT_PASS);
                 st = kLaneWalk;
             }
-        } else if (what == 1) {
-            // rounds of box steps while enough lanes take part
-            do {
-                const bool stepping = st == kLaneWalk && Trav::can_step(W);
-                Trav::fetch(S, lds, tq, W, stepping);  // every lane of the wave (the cooperative record fetch; nothing otherwise)
-                if (stepping) Trav::step(S, lds, tq, W COUNT_PASS);
-            } while ((uint32_t)__popcll(__ballot(st == kLaneWalk && Trav::can_step(W))) >= HPT_SM_T_STEP);
-        } else if (what == 2) {
-            // rounds of triangle tests: every lane that has a triangle to test takes part (also lanes
-            // that could still step: the round costs the same), until too few lanes are blocked
-            do {
-                if (st == kLaneWalk && Trav::may_test(W)) Trav::template test_one<kExt>(S, lds, tq, W COUNT_PASS);
-            } while ((uint32_t)__popcll(__ballot(st == kLaneWalk && Trav::wants_test(W))) >= HPT_SM_T_TRI);
         } else if (what == 3) {
             if (st == kLaneShadeA) {
                 f3 so, wi;
@@ -751,23 +779,7 @@ __device__ __forceinline__ void schedule_wave(const DevScene& S, const float4* l
                 st = kLaneWalk;
             }
         }
-        // walks that have just ended: the marking variants' back-face filter, then the lane goes to the shading
-        if (st == kLaneWalk) {
-            Trav::settle(S, lds, W COUNT_PASS);
-            if (Trav::done(W)) {
-                if (W.shadow) {
-                    st = kLaneShadeB;
-                } else {
-                    hit_tri = W.best;
-                    hit_t = W.best_t;
-                    if constexpr (kHave) {
-                        ls.normal = W.best_n;
-                        ls.material = W.best_m;
-                    }
-                    st = kLaneShadeA;
-                }
-            }
-        }
+        finish_walks();  // (a walk can end where it begins: the root's box is missed)
     }
 }
 

@@ -1139,13 +1139,18 @@ HD void walk_step_record(const DevScene& S, const float4 q0, const float4 q1, co
         float tfl, tfr;
         hl = box_range_finite(q0, q1, o, inv, tnl, tfl) && tfl >= behind && tnl <= W.cull_t;
         hr = box_range_finite(q2, q3, o, inv, tnr, tfr) && tfr >= behind && tnr <= W.cull_t;
-    } else if (W.finite) {
+    } else {
+        // The min/max form for every lane, in one block with its products: were it the branch of an `if (W.finite)`, the
+        // products would be formed ahead of the branch and the compiler, which then cannot see where the operands of
+        // the min/max come from, would put six canonicalising `v_max x, x, x` in front of them in every step.  The rare
+        // lane with a zero direction component replaces the answer by the reference's NaN-aware sequence.
         hl = box_hit_finite(q0, q1, o, inv);
         hr = box_hit_finite(q2, q3, o, inv);
-    } else {
-        const bool nx = W.d.x < 0, ny = W.d.y < 0, nz = W.d.z < 0;
-        hl = box_hit(q0, q1, o, inv, nx, ny, nz);
-        hr = box_hit(q2, q3, o, inv, nx, ny, nz);
+        if (!W.finite) {
+            const bool nx = W.d.x < 0, ny = W.d.y < 0, nz = W.d.z < 0;
+            hl = box_hit(q0, q1, o, inv, nx, ny, nz);
+            hr = box_hit(q2, q3, o, inv, nx, ny, nz);
+        }
     }
     const int rl = __float_as_int(q0.w), rr = __float_as_int(q1.w);
     if (hl && rl < 0) {
