@@ -662,7 +662,7 @@ template <int kScene, bool kExt, class Policy>
 __device__ __forceinline__ void schedule_wave(const DevScene& S, const float4* lds, TriQueue tq, int max_depth, Policy& pol COUNT_ARG) {
     using Trav = Traversal<kScene>;
     typename Trav::State W;
-    Trav::init(W);
+    Trav::init(W, tq);
     const ShadeSrc src = shade_source<kScene, kExt>(S, lds);
     int st = kLaneIdle;
     Path p;
@@ -675,7 +675,7 @@ __device__ __forceinline__ void schedule_wave(const DevScene& S, const float4* l
     auto finish_walks = [&]() {
         if (st == kLaneWalk) {
             Trav::settle(S, lds, W COUNT_PASS);
-            if (Trav::done(W)) {
+            if (Trav::done(W, tq)) {
                 if (W.shadow) {
                     st = kLaneShadeB;
                 } else {
@@ -695,15 +695,13 @@ __device__ __forceinline__ void schedule_wave(const DevScene& S, const float4* l
         // loop the path and shading state is untouched, so it stays where it is while the wave alternates between them.
         int what;  // 0 refill, 1 step, 2 triangles, 3 shade A, 4 shade B, -1 nothing left
         for (;;) {
-            const bool walking = st == kLaneWalk;
-            const bool can_step = walking && Trav::can_step(W);
-            const bool wants_test = walking && Trav::wants_test(W);
-            const uint32_t c_step = (uint32_t)__popcll(__ballot(can_step));
-            const uint32_t c_tri = (uint32_t)__popcll(__ballot(wants_test));
-            const uint32_t c_a = (uint32_t)__popcll(__ballot(st == kLaneShadeA));
-            const uint32_t c_b = (uint32_t)__popcll(__ballot(st == kLaneShadeB));
-            const unsigned long long m_idle = __ballot(st == kLaneIdle);
-            const uint32_t c_idle = m_idle ? pol.refillable(m_idle, __ballot(st != kLaneIdle)) : 0u;
+            const unsigned long long m_walk = lane_mask(st == kLaneWalk);
+            const uint32_t c_step = lane_count(m_walk & Trav::can_step_mask(W, tq));
+            const uint32_t c_tri = lane_count(m_walk & Trav::wants_test_mask(W, tq));
+            const uint32_t c_a = lane_count(lane_mask(st == kLaneShadeA));
+            const uint32_t c_b = lane_count(lane_mask(st == kLaneShadeB));
+            const unsigned long long m_idle = lane_mask(st == kLaneIdle);
+            const uint32_t c_idle = m_idle ? pol.refillable(m_idle, lane_mask(st != kLaneIdle)) : 0u;
             // what to run: the first kind of round that reaches its threshold, else the most wanted
             if (c_idle >= HPT_SM_T_REFILL) what = 0;
             else if (c_step >= HPT_SM_T_STEP) what = 1;
@@ -722,16 +720,16 @@ __device__ __forceinline__ void schedule_wave(const DevScene& S, const float4* l
             if (what == 1) {
                 // rounds of box steps while enough lanes take part
                 do {
-                    const bool stepping = st == kLaneWalk && Trav::can_step(W);
+                    const bool stepping = st == kLaneWalk && Trav::can_step(W, tq);
                     Trav::fetch(S, lds, tq, W, stepping);  // every lane of the wave (the cooperative record fetch; nothing otherwise)
                     if (stepping) Trav::step(S, lds, tq, W COUNT_PASS);
-                } while ((uint32_t)__popcll(__ballot(st == kLaneWalk && Trav::can_step(W))) >= HPT_SM_T_STEP);
+                } while (lane_count(m_walk & Trav::can_step_mask(W, tq)) >= HPT_SM_T_STEP);  // (no lane changes its state in here)
             } else if (what == 2) {
                 // rounds of triangle tests: every lane that has a triangle to test takes part (also lanes
                 // that could still step: the round costs the same), until too few lanes are blocked
                 do {
-                    if (st == kLaneWalk && Trav::may_test(W)) Trav::template test_one<kExt>(S, lds, tq, W COUNT_PASS);
-                } while ((uint32_t)__popcll(__ballot(st == kLaneWalk && Trav::wants_test(W))) >= HPT_SM_T_TRI);
+                    if (st == kLaneWalk && Trav::may_test(W, tq)) Trav::template test_one<kExt>(S, lds, tq, W COUNT_PASS);
+                } while (lane_count(m_walk & Trav::wants_test_mask(W, tq)) >= HPT_SM_T_TRI);
             } else {
                 break;
             }
@@ -743,7 +741,7 @@ __device__ __forceinline__ void schedule_wave(const DevScene& S, const float4* l
             pol.refill(st == kLaneIdle, p, got);
             if (got) {
                 pol.count_closest();
-                Trav::begin(S, lds, W, p.o, p.d, false, 0.f COUNT_PASS);
+                Trav::begin(S, lds, tq, W, p.o, p.d, false, 0.f COUNT_PASS);
                 st = kLaneWalk;
             }
         } else if (what == 3) {
@@ -756,7 +754,7 @@ __device__ __forceinline__ void schedule_wave(const DevScene& S, const float4* l
                     st = kLaneIdle;
                 } else if (rc == kShadeShadowRay) {
                     pol.count_shadow();
-                    Trav::begin(S, lds, W, so, wi, true, tmax COUNT_PASS);
+                    Trav::begin(S, lds, tq, W, so, wi, true, tmax COUNT_PASS);
                     lit = true;
                     st = kLaneWalk;
                 } else {
@@ -775,7 +773,7 @@ __device__ __forceinline__ void schedule_wave(const DevScene& S, const float4* l
             }
             if (pol.next_bounce(keep, p)) {  // this lane traces the path's next bounce itself
                 pol.count_closest();
-                Trav::begin(S, lds, W, p.o, p.d, false, 0.f COUNT_PASS);
+                Trav::begin(S, lds, tq, W, p.o, p.d, false, 0.f COUNT_PASS);
                 st = kLaneWalk;
             }
         }
@@ -795,7 +793,7 @@ struct WfPolicy {
     uint32_t lane;
     bool more = true;               // wave-uniform: the segment may still hold records nobody has taken
     uint32_t n_closest = 0, n_shadow = 0;
-    __device__ __forceinline__ uint32_t refillable(unsigned long long m_idle, unsigned long long) const { return more ? (uint32_t)__popcll(m_idle) : 0u; }
+    __device__ __forceinline__ uint32_t refillable(unsigned long long m_idle, unsigned long long) const { return more ? lane_count(m_idle) : 0u; }
     __device__ __forceinline__ void refill(bool idle, Path& p, bool& got) {
         const unsigned long long m = __ballot(idle);
         const uint32_t n = (uint32_t)__popcll(m);
@@ -887,7 +885,7 @@ struct MegaPolicy {
 
     __device__ __forceinline__ bool pool_has_items() const { return cur_open && cur_next < cur_total; }
     __device__ __forceinline__ uint32_t refillable(unsigned long long m_idle, unsigned long long) const {
-        return (pool_has_items() || !queue_empty) ? (uint32_t)__popcll(m_idle) : 0u;
+        return (pool_has_items() || !queue_empty) ? lane_count(m_idle) : 0u;
     }
     __device__ __forceinline__ void refill(bool idle, Path& p, bool& got) {
         const unsigned long long need = __ballot(idle);

@@ -78,6 +78,15 @@ struct f3 {
     float x, y, z;
 };
 #define HD __device__ __forceinline__
+
+// Lane mask of a predicate.  A compound predicate is best given as the AND of the masks of its comparisons: the
+// compiler turns ballot(a && b) into a 0/1 value per lane and a second comparison, two vector instructions that the
+// scalar AND of two comparison masks does not need.
+HD unsigned long long lane_mask(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// Lanes in a mask, as a 32-bit scalar (the 64-bit population count keeps its comparisons 64 bits wide, and a 64-bit
+// less-than is a vector instruction)
+HD uint32_t lane_count(unsigned long long m) { return (uint32_t)__builtin_popcount((uint32_t)m) + (uint32_t)__builtin_popcount((uint32_t)(m >> 32)); }
+
 HD f3 mk(float a, float b, float c) { return f3{a, b, c}; }
 HD f3 mk(float a) { return f3{a, a, a}; }
 HD f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -355,6 +364,9 @@ HD float4 lds_read(uint32_t at) {
     const raw_float4 v = *reinterpret_cast<lds_float4*>(static_cast<uintptr_t>(at));
     return make_float4(v.x, v.y, v.z, v.w);
 }
+typedef uint32_t __attribute__((address_space(3))) lds_word;
+HD uint32_t lds_read_word(uint32_t at) { return *reinterpret_cast<const lds_word*>(static_cast<uintptr_t>(at)); }
+HD void lds_write_word(uint32_t at, uint32_t v) { *reinterpret_cast<lds_word*>(static_cast<uintptr_t>(at)) = v; }
 
 // Stage the records a variant reads from LDS (the Cornell box: 20 KiB).  Every thread of the
 // workgroup must call it; it ends with a workgroup barrier (also for the variants that stage nothing).
@@ -1044,7 +1056,10 @@ HD void trace(const DevScene& S, const float4* __restrict__ lds, TriQueue tq, f3
 struct Walk {
     f3 o, d, inv;
     int cur;            // record to visit next, -1 = none left
-    uint32_t sp, cnt;   // stack entries, queued triangles
+    // Top of the lane's stack and end of its triangle queue as LDS byte addresses (the lane's entries lie
+    // 4 * blockDim.x bytes apart, from tq.stk / tq.q on): a push is a write and one addition, where an entry count
+    // would want a multiplication and a shift as well.  Empty: sp == address of tq.stk, qe == address of tq.q.
+    uint32_t sp, qe;
     int best;           // closest: best triangle so far; any-hit: the occluder found
     double best_t;
     float tmax;         // any-hit: Ray::shadowDistance (a float's value, Scene.hpp:203)
@@ -1055,12 +1070,16 @@ struct Walk {
     f3 best_n;
     uint32_t best_m;
 };
+// (a step may queue two triangles)
 template <int kScene>
-HD bool walk_can_step(const Walk& W) { return W.cur >= 0 && W.cnt + 2u <= tri_queue_entries(kScene); }
-HD bool walk_done(const Walk& W) { return W.cur < 0 && W.cnt == 0u; }
+HD bool walk_queue_has_room(const Walk& W, TriQueue tq) { return W.qe - lds_address(tq.q) <= (tri_queue_entries(kScene) - 2u) * 4u * tq.stride; }
+HD bool walk_queue_empty(const Walk& W, TriQueue tq) { return W.qe == lds_address(tq.q); }
+template <int kScene>
+HD bool walk_can_step(const Walk& W, TriQueue tq) { return W.cur >= 0 && walk_queue_has_room<kScene>(W, tq); }
+HD bool walk_done(const Walk& W, TriQueue tq) { return W.cur < 0 && walk_queue_empty(W, tq); }
 
 template <int kScene>
-HD void walk_begin(const DevScene& S, Walk& W, f3 o, f3 d, bool shadow, float tmax COUNT_ARG) {
+HD void walk_begin(const DevScene& S, TriQueue tq, Walk& W, f3 o, f3 d, bool shadow, float tmax COUNT_ARG) {
     constexpr bool kCull = (kScene == kScenePairCull);
     W.o = o;
     W.d = d;
@@ -1071,8 +1090,8 @@ HD void walk_begin(const DevScene& S, Walk& W, f3 o, f3 d, bool shadow, float tm
     W.tmax = tmax;
     W.best = -1;
     W.best_t = (double)kInfinity;
-    W.sp = 0u;
-    W.cnt = 0u;
+    W.sp = lds_address(tq.stk);
+    W.qe = lds_address(tq.q);
     W.cull_t = shadow ? (float)((double)tmax - (double)kEpsilon4) * 1.000001f + S.cull_slack : kInf;
     const float4 rlo = make_float4(S.root_lo[0], S.root_lo[1], S.root_lo[2], 0.f);
     const float4 rhi = make_float4(S.root_hi[0], S.root_hi[1], S.root_hi[2], 0.f);
@@ -1153,13 +1172,14 @@ HD void walk_step_record(const DevScene& S, const float4 q0, const float4 q1, co
         }
     }
     const int rl = __float_as_int(q0.w), rr = __float_as_int(q1.w);
+    const uint32_t pitch = 4u * tq.stride;
     if (hl && rl < 0) {
-        tq.q[__umul24(W.cnt, tq.stride)] = (uint32_t)~rl;
-        ++W.cnt;
+        lds_write_word(W.qe, (uint32_t)~rl);
+        W.qe += pitch;
     }
     if (hr && rr < 0) {
-        tq.q[__umul24(W.cnt, tq.stride)] = (uint32_t)~rr;
-        ++W.cnt;
+        lds_write_word(W.qe, (uint32_t)~rr);
+        W.qe += pitch;
     }
     const bool gl = hl && rl >= 0, gr = hr && rr >= 0;
     if (gl && gr) {
@@ -1167,22 +1187,22 @@ HD void walk_step_record(const DevScene& S, const float4 q0, const float4 q1, co
             const bool right_first = tnr < tnl;
             const float tfar_child = right_first ? tnl : tnr;
             const uint32_t qd = (uint32_t)fminf(fmaxf(tfar_child, 0.f) * S.cull_qscale, 1023.f);
-            tq.stk[__umul24(W.sp, tq.stride)] = (uint32_t)(right_first ? rl : rr) | (qd << 22);
+            lds_write_word(W.sp, (uint32_t)(right_first ? rl : rr) | (qd << 22));
             W.cur = right_first ? rr : rl;
         } else {
-            tq.stk[__umul24(W.sp, tq.stride)] = (uint32_t)rr;
+            lds_write_word(W.sp, (uint32_t)rr);
             W.cur = rl;
         }
-        ++W.sp;
+        W.sp += pitch;
     } else if (gl) {
         W.cur = rl;
     } else if (gr) {
         W.cur = rr;
     } else {
         W.cur = -1;
-        while (W.sp) {
-            --W.sp;
-            uint32_t e = tq.stk[__umul24(W.sp, tq.stride)];
+        while (W.sp != lds_address(tq.stk)) {
+            W.sp -= pitch;
+            uint32_t e = lds_read_word(W.sp);
             if constexpr (kCull) {
                 if ((float)(e >> 22) * S.cull_qinv > W.cull_t) continue;
                 e &= 0x3FFFFFu;
@@ -1193,12 +1213,12 @@ HD void walk_step_record(const DevScene& S, const float4 q0, const float4 q1, co
     }
 }
 
-// test the triangle queued last (requires W.cnt > 0)
+// test the triangle queued last (requires a queue that is not empty)
 template <int kScene, bool kSpheres = true>
 HD void walk_test_one(const DevScene& S, const float4* __restrict__ T, TriQueue tq, Walk& W COUNT_ARG) {
     constexpr bool kCull = (kScene == kScenePairCull);
-    --W.cnt;
-    const int tri = (int)tq.q[__umul24(W.cnt, tq.stride)];
+    W.qe -= 4u * tq.stride;
+    const int tri = (int)lds_read_word(W.qe);
     double t;
     COUNT_TRI(1);
     const float4 r0 = T[4 * tri], r1 = T[4 * tri + 1], r2 = T[4 * tri + 2], r3 = T[4 * tri + 3];  // one fetch of the whole record
@@ -1208,8 +1228,8 @@ HD void walk_test_one(const DevScene& S, const float4* __restrict__ T, TriQueue 
                 W.best = tri;
                 W.best_t = t;
                 W.cur = -1;
-                W.sp = 0u;
-                W.cnt = 0u;
+                W.sp = lds_address(tq.stk);
+                W.qe = lds_address(tq.q);
             }
         } else if (t < W.best_t || (t == W.best_t && tri < W.best)) {
             W.best = tri;
@@ -1253,19 +1273,22 @@ template <int kScene>
 struct PairTraversal {
     using State = Walk;
     static constexpr bool kKeepsHitData = true;  // (for test_one<false>) State::best_n / best_m describe State::best
-    HD static void init(State& W) {
+    HD static void init(State& W, TriQueue tq) {
         W.cur = -1;
-        W.cnt = 0u;
+        W.qe = lds_address(tq.q);
     }
     HD static const float4* records(const DevScene& S, const float4* lds) { return kScene == kScenePairLds ? lds : S.pairs; }
     HD static const float4* triangles(const DevScene& S, const float4* lds) { return kScene == kScenePairLds ? lds + 4u * S.num_pairs : S.tris; }
-    HD static void begin(const DevScene& S, const float4* lds, State& W, f3 o, f3 d, bool shadow, float tmax COUNT_ARG) {
-        walk_begin<kScene>(S, W, o, d, shadow, tmax COUNT_PASS);
+    HD static void begin(const DevScene& S, const float4* lds, TriQueue tq, State& W, f3 o, f3 d, bool shadow, float tmax COUNT_ARG) {
+        walk_begin<kScene>(S, tq, W, o, d, shadow, tmax COUNT_PASS);
     }
-    HD static bool can_step(const State& W) { return walk_can_step<kScene>(W); }
-    HD static bool wants_test(const State& W) { return !walk_can_step<kScene>(W) && W.cnt > 0u; }
-    HD static bool may_test(const State& W) { return W.cnt > 0u; }
-    HD static bool done(const State& W) { return walk_done(W); }
+    HD static bool can_step(const State& W, TriQueue tq) { return walk_can_step<kScene>(W, tq); }
+    HD static bool wants_test(const State& W, TriQueue tq) { return !walk_can_step<kScene>(W, tq) && !walk_queue_empty(W, tq); }
+    // the same two as lane masks (every lane of the wave calls them)
+    HD static unsigned long long can_step_mask(const State& W, TriQueue tq) { return lane_mask(W.cur >= 0) & lane_mask(walk_queue_has_room<kScene>(W, tq)); }
+    HD static unsigned long long wants_test_mask(const State& W, TriQueue tq) { return ~can_step_mask(W, tq) & lane_mask(!walk_queue_empty(W, tq)); }
+    HD static bool may_test(const State& W, TriQueue tq) { return !walk_queue_empty(W, tq); }
+    HD static bool done(const State& W, TriQueue tq) { return walk_done(W, tq); }
     // A round of steps: `fetch` is called by EVERY lane of the wave (stepping = this lane takes part), then `step` by the
     // lanes that take part.  Only the cooperative record fetch does anything in `fetch`.
     HD static void fetch(const DevScene& S, const float4* lds, TriQueue tq, const State& W, bool stepping) {
@@ -1291,13 +1314,13 @@ struct MarkTraversal {
     static constexpr bool kKeepsHitData = false;
     using State = MarkWalk<kMask32>;
     using mask_t = typename State::mask_t;
-    HD static void init(State& W) {
+    HD static void init(State& W, TriQueue) {
         W.at = W.stop = 0u;
         W.pending = 0;
         W.filtered = true;
     }
     HD static const float4* triangles(const DevScene& S, const float4* lds) { return lds + 18u * S.num_nodes; }
-    HD static void begin(const DevScene& S, const float4* lds, State& W, f3 o, f3 d, bool shadow, float tmax COUNT_ARG) {
+    HD static void begin(const DevScene& S, const float4* lds, TriQueue, State& W, f3 o, f3 d, bool shadow, float tmax COUNT_ARG) {
         W.o = o;
         W.d = d;
         W.inv = mk(rcp_rn(d.x), rcp_rn(d.y), rcp_rn(d.z));  // == float(1. / double(d)), Ray.hpp:21
@@ -1321,10 +1344,12 @@ struct MarkTraversal {
         }
     }
     HD static void fetch(const DevScene&, const float4*, TriQueue, const State&, bool) {}
-    HD static bool can_step(const State& W) { return W.at < W.stop; }
-    HD static bool wants_test(const State& W) { return W.at >= W.stop && W.pending != 0; }
-    HD static bool may_test(const State& W) { return W.at >= W.stop && W.filtered && W.pending != 0; }
-    HD static bool done(const State& W) { return W.at >= W.stop && W.filtered && W.pending == 0; }
+    HD static bool can_step(const State& W, TriQueue) { return W.at < W.stop; }
+    HD static bool wants_test(const State& W, TriQueue) { return W.at >= W.stop && W.pending != 0; }
+    HD static unsigned long long can_step_mask(const State& W, TriQueue) { return lane_mask(W.at < W.stop); }
+    HD static unsigned long long wants_test_mask(const State& W, TriQueue) { return lane_mask(W.at >= W.stop) & lane_mask(W.pending != 0); }
+    HD static bool may_test(const State& W, TriQueue) { return W.at >= W.stop && W.filtered && W.pending != 0; }
+    HD static bool done(const State& W, TriQueue) { return W.at >= W.stop && W.filtered && W.pending == 0; }
     HD static void step(const DevScene& S, const float4* lds, TriQueue, State& W COUNT_ARG) {
         COUNT_BOX(1);
         const float4 nr = lds_read(W.at), fr = lds_read(W.at + 16u);
