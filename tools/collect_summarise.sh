@@ -14,7 +14,7 @@ python tools/pmc_to_json.py gpurun_out/pmc_${TAG}_cornell_m1 k_render_mega corne
 python tools/pmc_to_json.py gpurun_out/pmc_${TAG}_bunny_m2 k_wf_bounces bunny_mode2_1024x1024_d20_spp256 $P/${TAG}_bunny_mode2_pmc_summary.txt > /dev/null
 python tools/pmc_to_json.py gpurun_out/pmc_${TAG}_hf_m2 k_wf_bounces heightfield:708_mode2_2048x2048_d20_spp64 $P/${TAG}_heightfield708_mode2_pmc_summary.txt > /dev/null
 for s in cornell_m1 bunny_m2 hf_m2; do
-  f=$(ls gpurun_out/pmc_${TAG}_$s/trace/*/*kernel_stats.csv | head -1)
+  f=$(ls -t gpurun_out/pmc_${TAG}_$s/trace/*/*kernel_stats.csv | head -1)   # the newest (the directory may hold earlier collections)
   cp $f $P/${TAG}_${s}_kernel_stats.csv
 done
 ls $P | grep "^$TAG" 

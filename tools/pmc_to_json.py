@@ -16,7 +16,18 @@ import sys
 root, sub, key = sys.argv[1], sys.argv[2], sys.argv[3]
 tot = collections.defaultdict(float)
 disp = collections.defaultdict(set)
-for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+def newest_per_directory(pattern):
+    """One file per directory, the newest: a directory merged from several collections of the same tag (gpurun_out is
+    merged into, never cleared) would otherwise average the counters of different builds."""
+    best = {}
+    for f in glob.glob(pattern, recursive=True):
+        d = os.path.dirname(f)
+        if d not in best or os.path.getmtime(f) > os.path.getmtime(best[d]):
+            best[d] = f
+    return sorted(best.values())
+
+
+for f in newest_per_directory(os.path.join(root, "**", "*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         if sub in r["Kernel_Name"]:
             tot[r["Counter_Name"]] += float(r["Counter_Value"])
@@ -26,7 +37,7 @@ if not per.get("SQ_INSTS_VALU") or "FETCH_SIZE" not in per:
     sys.exit("no counters of a kernel matching %r under %s: nothing written" % (sub, root))
 lines = ["%-30s %18.0f  per-dispatch %16.0f  (%d dispatches)" % (k, tot[k], per[k], len(disp[k])) for k in sorted(tot)]
 # kernel durations from the trace pass
-for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True):
+for f in newest_per_directory(os.path.join(root, "trace", "**", "*kernel_stats.csv")):
     for r in csv.DictReader(open(f)):
         lines.append("kernel_stats: %s calls %s avg_ns %s pct %s" % (r["Name"][:60], r["Calls"], r["AverageNs"], r["Percentage"]))
 entry = {
