@@ -196,10 +196,13 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        # (a collective that cannot complete ends the run with an error after three minutes instead of holding the node)
+        import datetime
+        limit = datetime.timedelta(seconds=int(os.environ.get("HPT_BENCH_COLLECTIVE_TIMEOUT", "180")))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=limit)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=limit)
 
     def reduce_sum(t):
         reduce_accum(t, dist, 0)
