@@ -2060,7 +2060,16 @@ int render_launch(hpt_ctx* ctx, int mode, int block, int max_depth, uint32_t sam
         uint32_t* live = nullptr;
         for (;;) {
             const uint64_t cap_groups = (cap + 63ull) >> 6;
-            segments = (uint32_t)std::min<uint64_t>((uint64_t)per_cu * (uint64_t)ctx->num_cus, cap_groups);
+            // The lock-step kernels get 16 workgroups (segments) per resident slot: a segment's late bounces hold few
+            // paths, and with one generation of workgroups every compute unit is in that thin tail at the same time;
+            // with several, the tail of one workgroup runs beside the first bounces of the next (Cornell box, 2^28
+            // paths per batch: 27.0 Grays/s with 1 generation, 28.7 / 30.2 / 31.5 / 31.9 / 31.6 / 30.7 with 2 / 4 / 8 /
+            // 16 / 32 / 64).  Under the wave scheduler the lanes of a thin wave are refilled anyway and more
+            // generations gain nothing (bunny +1 %, 1.0 M-triangle height field -2 % at 4).  HPT_WF_GENERATIONS overrides.
+            uint64_t generations = scheduler ? 1u : 16u;
+            if (const char* e = getenv("HPT_WF_GENERATIONS")) generations = (uint64_t)std::max(1, atoi(e));
+            if (fixed) generations = 1;  // (the fixed buffers hold one live counter per resident workgroup)
+            segments = (uint32_t)std::min<uint64_t>(generations * (uint64_t)per_cu * (uint64_t)ctx->num_cus, cap_groups);
             if (fixed) segments = (uint32_t)std::min<uint64_t>(segments, fixed->live_slots);
             seg = (uint32_t)((cap_groups + segments - 1ull) / segments) * 64u;  // records per segment
             if (fixed) {
