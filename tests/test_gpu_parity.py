@@ -307,6 +307,22 @@ def test_wavefront_small_capacity_batches(hp, oracle, gpu_ctx):
     assert np.array_equal(got.view(np.int32), oracle.resolve(want_acc, spp).view(np.int32))
 
 
+@pytest.mark.parametrize("generations", ["1", "3", "16", "200"])
+def test_wavefront_segment_generations(hp, oracle, gpu_ctx, monkeypatch, generations):
+    """The streamed mode deals a batch's paths to more queue segments than workgroups are resident at once (16 per slot
+    for the lock-step kernels, so that the thin late bounces of one workgroup overlap the first bounces of the next);
+    HPT_WF_GENERATIONS sets the number.  However many there are, the sums are the oracle's bit for bit."""
+    w, h, depth, spp = 200, 160, 9, 6
+    sc = hp.Scene.CreateBuiltinScene(hp.Scene.CornellBox, depth, w, h)
+    monkeypatch.setenv("HPT_WF_GENERATIONS", generations)
+    gpu_ctx.upload(sc)
+    gpu_ctx.accum_clear()
+    gpu_ctx.render(2, 256, depth, 0, spp)
+    got = gpu_ctx.resolve(spp)
+    want_acc, _ = oracle.cornell(w, h).render(RNG_PHILOX, TRIG_PORTABLE, depth, spp, fixed=True)
+    assert np.array_equal(got.view(np.int32), oracle.resolve(want_acc, spp).view(np.int32))
+
+
 def test_wavefront_queues_shrink_when_the_card_is_full(hp, monkeypatch):
     """The streamed mode sizes its two path queues for the call (up to 2^28 paths, 32 GiB); when the card cannot give
     that much it halves the batch until the queues fit, and the sums are the same.  Card fullness is simulated with
